@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's interface for the render hot path.
+
+Names follow the reference (``TileRenderer.render/generateTiles/lastErrors``, ``Config`` =
+``RayTracer::Config``, ``MeshBuilder.buildScene/buildDefaultScene``), argument meaning and error
+behaviour too; every render goes through the C ABI of ``libmcrt.so`` into the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import abi
+from ._lib import McrtError, check, load
+from .abi import Config, Mesh, Scene, SceneDescHolder, Texture
+
+Image = np.ndarray  # (H, W, 4) float32 — skin/image.h:9-15
+
+
+def device_count() -> int:
+    return int(load().mcrt_device_count())
+
+
+class SceneDesc:
+    """A scene description the library can consume: either built from a Python ``Scene`` or owned by
+    the native scene builder.  ``.ptr`` is a ``POINTER(McrtSceneDesc)``-compatible object."""
+
+    def __init__(self, scene: Optional[Scene] = None, _native=None):
+        self._holder = SceneDescHolder(scene) if scene is not None else None
+        self._native = _native
+
+    @property
+    def ptr(self):
+        return self._native if self._native is not None else self._holder.ptr
+
+    @property
+    def desc(self) -> abi.McrtSceneDesc:
+        return self._native.contents if self._native is not None else self._holder.desc
+
+    def to_numpy(self) -> dict:
+        return abi.desc_to_numpy(self.desc)
+
+    def __del__(self):
+        if getattr(self, "_native", None) is not None:
+            try:
+                load().mcrt_scene_desc_free(self._native)
+            except Exception:
+                pass
+            self._native = None
+
+
+def _as_desc(scene) -> SceneDesc:
+    if isinstance(scene, SceneDesc):
+        return scene
+    if isinstance(scene, Scene):
+        return SceneDesc(scene)
+    raise TypeError("scene must be a Scene or SceneDesc")
+
+
+class MeshBuilder:
+    """scene/mesh_builder.h:7-34 (scene construction from skin data; native implementation)."""
+
+    @staticmethod
+    def buildScene(skin_rgba8: np.ndarray, pose: Optional[Sequence[float]] = None) -> SceneDesc:
+        """SkinParser::parse (64x64 / 64x32 RGBA8) + MeshBuilder::buildScene."""
+        skin = np.ascontiguousarray(skin_rgba8, np.uint8)
+        if skin.ndim != 3 or skin.shape[2] != 4:
+            raise ValueError("skin must be (H, W, 4) uint8")
+        h, w = skin.shape[:2]
+        p = np.asarray(pose if pose is not None else [0.0] * 12, np.float32)
+        out = C.POINTER(abi.McrtSceneDesc)()
+        rc = load().mcrt_build_skin_scene(skin.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, abi.fptr(p), C.byref(out))
+        if rc != 0:
+            # skin_parser.cpp:122-131: only 64x64 and 64x32 are valid
+            raise ValueError(f"Invalid skin dimensions: {w}x{h} (expected 64x64 or 64x32)")
+        return SceneDesc(_native=out)
+
+    @staticmethod
+    def buildDefaultScene(pose: Optional[Sequence[float]] = None) -> SceneDesc:
+        p = np.asarray(pose if pose is not None else [0.0] * 12, np.float32)
+        out = C.POINTER(abi.McrtSceneDesc)()
+        check(load().mcrt_build_default_scene(abi.fptr(p), C.byref(out)))
+        return SceneDesc(_native=out)
+
+
+def getBuiltinPoses() -> List[np.ndarray]:
+    """scene/pose.h:25-92 → 7 poses x 12 floats ({head, body, rArm, lArm, rLeg, lLeg} x {rotX, rotZ})."""
+    out = []
+    for i in range(7):
+        p = np.zeros(12, np.float32)
+        check(load().mcrt_builtin_pose(i, abi.fptr(p)))
+        out.append(p)
+    return out
+
+
+class TileRenderer:
+    """raytracer/tile_renderer.h:16-47."""
+
+    _errors: List[Tuple[int, str]] = []
+
+    @staticmethod
+    def generateTiles(imageWidth: int, imageHeight: int, tileSize: int) -> List[Tuple[int, int, int, int]]:
+        lib = load()
+        n = lib.mcrt_generate_tiles(imageWidth, imageHeight, tileSize, None, 0)
+        arr = (abi.McrtTile * max(n, 1))()
+        lib.mcrt_generate_tiles(imageWidth, imageHeight, tileSize, arr, n)
+        return [(arr[i].x, arr[i].y, arr[i].width, arr[i].height) for i in range(n)]
+
+    @staticmethod
+    def render(scene, config: Config, progressCallback: Optional[Callable[[int, int], None]] = None,
+               device: int = 0) -> Image:
+        """TileRenderer::render.  Per-frame failures never raise (tile_renderer.cpp:158-166): they are
+        recorded as one ``(-1, message)`` entry in ``lastErrors()`` and the image keeps Color() =
+        (0,0,0,1) pixels."""
+        lib = load()
+        d = _as_desc(scene)
+        c = config.to_c()
+        w, h = max(config.width, 0), max(config.height, 0)
+        out = np.zeros((h, w, 4), np.float32)
+        out[..., 3] = 1.0  # Image(w,h): default Color() = (0,0,0,1)
+        TileRenderer._errors = []
+        if w == 0 or h == 0 or config.tileSize <= 0:
+            return out
+        cb = abi.PROGRESS_FN((lambda done, total, _u: progressCallback(done, total))) if progressCallback else C.cast(None, abi.PROGRESS_FN)
+        rc = lib.mcrt_render(d.ptr, C.byref(c), abi.fptr(out), cb, None, device)
+        if rc != 0:
+            TileRenderer._errors = [(-1, lib.mcrt_last_error().decode("utf-8", "replace"))]
+            out[...] = 0.0
+            out[..., 3] = 1.0
+        return out
+
+    @staticmethod
+    def lastErrors() -> List[Tuple[int, str]]:
+        return list(TileRenderer._errors)
+
+    @staticmethod
+    def lastTimings() -> dict:
+        t = abi.McrtTimings()
+        load().mcrt_last_timings(C.byref(t))
+        return {k: getattr(t, k) for k, _ in abi.McrtTimings._fields_}
+
+
+def quantize_rgba8(image: np.ndarray) -> np.ndarray:
+    """ImageWriter quantiser (image_writer.cpp:18-22): (H, W, 4) float32 → uint8."""
+    img = np.ascontiguousarray(image, np.float32)
+    out = np.zeros(img.shape, np.uint8)
+    load().mcrt_quantize_rgba8(abi.fptr(img), out.ctypes.data_as(C.POINTER(C.c_uint8)), img.size // 4)
+    return out
+
+
+class DeviceScene:
+    """A flattened scene resident in HBM on one device (mcrt_scene).  Renders go to device pointers
+    (e.g. ``torch.Tensor.data_ptr()``) on a caller-chosen HIP stream."""
+
+    def __init__(self, scene, device: int = 0):
+        self._desc = _as_desc(scene)
+        self._h = C.c_void_p()
+        self.device = device
+        check(load().mcrt_scene_create(self._desc.ptr, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().mcrt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def owned_pixel_rows(self, config: Config, first: int = 0, step: int = 1) -> int:
+        c = config.to_c()
+        return int(load().mcrt_owned_pixel_rows(C.byref(c), first, step))
+
+    def render_device(self, config: Config, out_ptr: int, first: int = 0, step: int = 1,
+                      layout: int = abi.LAYOUT_FRAME, stream: int = 0) -> None:
+        c = config.to_c()
+        check(load().mcrt_render_device(self._h, C.byref(c), first, step, layout, C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def time_render_device(self, config: Config, out_ptr: int, iters: int, first: int = 0, step: int = 1,
+                           layout: int = abi.LAYOUT_FRAME, stream: int = 0) -> Tuple[float, float]:
+        """Returns (avg ms per render, avg ms of the trace kernel), measured with hipEvents on `stream`."""
+        c = config.to_c()
+        a, b = C.c_float(), C.c_float()
+        check(load().mcrt_time_render_device(self._h, C.byref(c), first, step, layout, C.c_void_p(out_ptr),
+                                             C.c_void_p(stream), iters, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    # ---- probes (per-function parity tests) ----
+    def intersect(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(len(rays), abi.HIT_DTYPE)
+        check(load().mcrt_probe_intersect(self._h, abi.fptr(rays), len(rays), out.ctypes.data))
+        return out
+
+    def trace(self, config: Config, rays: np.ndarray, depth: int = 0) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((len(rays), 4), np.float32)
+        c = config.to_c()
+        check(load().mcrt_probe_trace(self._h, C.byref(c), abi.fptr(rays), len(rays), depth, abi.fptr(out)))
+        return out
+
+
+def unpack_rows_device(config: Config, first: int, step: int, packed_ptr: int, frame_ptr: int, stream: int = 0) -> None:
+    c = config.to_c()
+    check(load().mcrt_unpack_rows_device(C.byref(c), first, step, C.c_void_p(packed_ptr), C.c_void_p(frame_ptr), C.c_void_p(stream)))
+
+
+def quantize_rgba8_device(rgba_ptr: int, out_ptr: int, n_pixels: int, stream: int = 0) -> None:
+    check(load().mcrt_quantize_rgba8_device(C.c_void_p(rgba_ptr), C.c_void_p(out_ptr), n_pixels, C.c_void_p(stream)))
+
+
+def probe_mt_uniform(seeds: Sequence[int], n_draws: int, device: int = 0) -> np.ndarray:
+    s = np.asarray(seeds, np.uint32)
+    out = np.zeros((len(s), n_draws), np.float32)
+    check(load().mcrt_probe_mt_uniform(device, s.ctypes.data_as(C.POINTER(C.c_uint32)), len(s), n_draws, abi.fptr(out)))
+    return out
+
+
+def probe_detmath(op: int, x: np.ndarray, y: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    yy = np.ascontiguousarray(y, np.float32) if y is not None else None
+    out = np.zeros_like(x)
+    check(load().mcrt_probe_detmath(device, op, abi.fptr(x), abi.fptr(yy) if yy is not None else None, x.size, abi.fptr(out)))
+    return out
+
+
+def probe_detmath_range(op: int, lo_bits: int, hi_bits: int, y0: float = 0.0, device: int = 0) -> int:
+    bad = C.c_uint64()
+    check(load().mcrt_probe_detmath_range(device, op, lo_bits, hi_bits, C.c_float(y0), C.byref(bad)))
+    return int(bad.value)
+
+
+def flatten(scene) -> bytes:
+    d = _as_desc(scene)
+    lib = load()
+    n = lib.mcrt_scene_flatten(d.ptr, None, 0)
+    if n == 0:
+        raise McrtError(abi.MCRT_ERR_INVALID, lib.mcrt_last_error().decode("utf-8", "replace"))
+    buf = C.create_string_buffer(n)
+    lib.mcrt_scene_flatten(d.ptr, buf, n)
+    return buf.raw

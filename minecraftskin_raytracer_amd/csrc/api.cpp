@@ -1,0 +1,449 @@
+// api.cpp — C-ABI implementation of include/mcrt.h (host side; kernels in render_kernels.hip).
+//
+// There is deliberately no CPU fallback anywhere in this file: every render / probe entry point
+// needs a HIP device and fails with MCRT_ERR_NO_DEVICE / MCRT_ERR_HIP otherwise.
+#include "flatten.h"
+#include "kernels.h"
+#include "mcrt.h"
+#include "mcrt_detmath.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace mcrt;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local mcrt_timings g_timings = {0, 0, 0, 0, 0};
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? MCRT_ERR_NO_DEVICE : MCRT_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(call)                                    \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&ptr, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer() { release(); }
+};
+
+bool valid_frame(const mcrt_config* c) { return c->width > 0 && c->height > 0 && c->tile_size > 0; }
+
+int draws_per_sample(const mcrt_config& c) {
+    int spp = c.samples_per_pixel > 1 ? c.samples_per_pixel : 1;
+    return (spp > 1 ? 2 : 0) + ((c.dof_enabled && c.aperture > 1e-6f) ? 2 : 0);
+}
+
+}  // namespace
+
+struct mcrt_scene {
+    int device = 0;
+    DeviceBuffer blob;
+    DeviceBuffer tile_rng, hit_rng, deep_stack;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+// fill RenderParams + make sure the workspace exists (allocation only when it has to grow)
+int prepare(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, RenderParams& p) {
+    std::memset(&p, 0, sizeof p);
+    p.scene = static_cast<const uint8_t*>(s->blob.ptr);
+    p.cfg = *cfg;
+    p.shard = make_shard(*cfg, first, step);
+    p.layout = layout;
+    p.out = d_out;
+    p.draws_per_sample = draws_per_sample(*cfg);
+    p.grid_blocks = render_grid_blocks(p);
+    HIP_TRY(s->tile_rng.reserve(tile_rng_bytes(p)));
+    HIP_TRY(s->hit_rng.reserve(hit_rng_bytes(p)));
+    HIP_TRY(s->deep_stack.reserve(deep_stack_bytes(p)));
+    p.tile_rng = tile_rng_bytes(p) ? static_cast<uint32_t*>(s->tile_rng.ptr) : nullptr;
+    p.hit_rng = hit_rng_bytes(p) ? static_cast<uint32_t*>(s->hit_rng.ptr) : nullptr;
+    p.deep_stack = deep_stack_bytes(p) ? static_cast<float*>(s->deep_stack.ptr) : nullptr;
+    return MCRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcrt_abi_version(void) { return MCRT_ABI_VERSION; }
+
+int mcrt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mcrt_last_error(void) { return g_err.c_str(); }
+
+void mcrt_config_init(mcrt_config* c) {  // raytracer.h:10-38
+    if (!c) return;
+    c->width = 256;
+    c->height = 256;
+    c->max_bounces = 3;
+    c->samples_per_pixel = 1;
+    c->tile_size = 32;
+    c->thread_count = 0;
+    c->soft_shadows = 1;
+    c->shadow_samples = 8;
+    c->ao_enabled = 0;
+    c->ao_samples = 8;
+    c->ao_radius = 3.0f;
+    c->ao_intensity = 0.5f;
+    c->dof_enabled = 0;
+    c->aperture = 0.5f;
+    c->focus_distance = 0.0f;
+    c->gradient_bg = 1;
+    c->gradient_scale = 1.0f;
+    const float center[4] = {0.91f, 0.89f, 0.86f, 1.0f}, edge[4] = {0.56f, 0.63f, 0.71f, 1.0f};
+    std::memcpy(c->bg_center, center, 16);
+    std::memcpy(c->bg_edge, edge, 16);
+}
+
+int mcrt_generate_tiles(int w, int h, int ts, mcrt_tile* tiles, int capacity) {  // tile_renderer.cpp:18-39
+    if (w <= 0 || h <= 0 || ts <= 0) return 0;
+    int cols = (w + ts - 1) / ts, rows = (h + ts - 1) / ts;
+    int n = 0;
+    for (int ty = 0; ty < rows; ++ty)
+        for (int tx = 0; tx < cols; ++tx, ++n) {
+            if (!tiles || n >= capacity) continue;
+            mcrt_tile& t = tiles[n];
+            t.x = tx * ts;
+            t.y = ty * ts;
+            t.width = ts < w - t.x ? ts : w - t.x;
+            t.height = ts < h - t.y ? ts : h - t.y;
+        }
+    return n;
+}
+
+size_t mcrt_scene_flatten(const mcrt_scene_desc* desc, void* blob, size_t capacity) {
+    std::vector<uint8_t> b;
+    std::string err;
+    if (!flatten_scene(desc, b, err)) {
+        g_err = err;
+        return 0;
+    }
+    if (blob && capacity) std::memcpy(blob, b.data(), b.size() < capacity ? b.size() : capacity);
+    return b.size();
+}
+
+int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out) {
+    if (!out) return fail(MCRT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    std::vector<uint8_t> b;
+    std::string err;
+    if (!flatten_scene(desc, b, err)) return fail(MCRT_ERR_INVALID, err);
+    int n = mcrt_device_count();
+    if (n <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(MCRT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    mcrt_scene* s = new mcrt_scene();
+    s->device = device;
+    hipError_t e = s->blob.reserve(b.size());
+    if (e == hipSuccess) e = hipMemcpy(s->blob.ptr, b.data(), b.size(), hipMemcpyHostToDevice);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&s->ev[i]);
+    if (e != hipSuccess) {
+        mcrt_scene_destroy(s);
+        return hip_fail(e, "scene upload");
+    }
+    *out = s;
+    return MCRT_OK;
+}
+
+void mcrt_scene_destroy(mcrt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    s->blob.release();
+    s->tile_rng.release();
+    s->hit_rng.release();
+    s->deep_stack.release();
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int mcrt_owned_pixel_rows(const mcrt_config* cfg, int first, int step) {
+    if (!cfg || !valid_frame(cfg)) return 0;
+    Shard sh = make_shard(*cfg, first, step);
+    return sh.owned_rows * cfg->tile_size;
+}
+
+int mcrt_render_device(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out,
+                       void* stream) {
+    if (!s || !cfg || !d_out) return fail(MCRT_ERR_INVALID, "NULL argument");
+    if (!valid_frame(cfg)) return MCRT_OK;  // zero tiles
+    if (first < 0 || step < 1) return fail(MCRT_ERR_INVALID, "tile_row_first must be >= 0 and tile_row_step >= 1");
+    HIP_TRY(hipSetDevice(s->device));
+    RenderParams p;
+    int rc = prepare(s, cfg, first, step, layout, d_out, p);
+    if (rc != MCRT_OK) return rc;
+    HIP_TRY(launch_render(p, static_cast<hipStream_t>(stream), nullptr, nullptr));
+    return MCRT_OK;
+}
+
+int mcrt_time_render_device(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out,
+                            void* stream, int iters, float* avg_render_ms, float* avg_trace_kernel_ms) {
+    if (!s || !cfg || !d_out || iters < 1) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (!valid_frame(cfg)) return fail(MCRT_ERR_INVALID, "empty frame");
+    HIP_TRY(hipSetDevice(s->device));
+    RenderParams p;
+    int rc = prepare(s, cfg, first, step, layout, d_out, p);
+    if (rc != MCRT_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double sum_render = 0.0, sum_kernel = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        HIP_TRY(hipEventRecord(s->ev[0], st));
+        HIP_TRY(launch_render(p, st, s->ev[1], s->ev[2]));
+        HIP_TRY(hipEventRecord(s->ev[3], st));
+        HIP_TRY(hipEventSynchronize(s->ev[3]));
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+        sum_render += a;
+        sum_kernel += b;
+    }
+    if (avg_render_ms) *avg_render_ms = static_cast<float>(sum_render / iters);
+    if (avg_trace_kernel_ms) *avg_trace_kernel_ms = static_cast<float>(sum_kernel / iters);
+    return MCRT_OK;
+}
+
+int mcrt_unpack_rows_device(const mcrt_config* cfg, int first, int step, const float* d_packed, float* d_frame,
+                            void* stream) {
+    if (!cfg || !d_packed || !d_frame) return fail(MCRT_ERR_INVALID, "NULL argument");
+    if (!valid_frame(cfg)) return MCRT_OK;
+    Shard sh = make_shard(*cfg, first, step);
+    HIP_TRY(launch_unpack_rows(*cfg, sh, d_packed, d_frame, static_cast<hipStream_t>(stream)));
+    return MCRT_OK;
+}
+
+int mcrt_quantize_rgba8_device(const float* d_rgba, uint8_t* d_out, size_t n_pixels, void* stream) {
+    if (!d_rgba || !d_out) return fail(MCRT_ERR_INVALID, "NULL argument");
+    HIP_TRY(launch_quantize(d_rgba, d_out, n_pixels, static_cast<hipStream_t>(stream)));
+    return MCRT_OK;
+}
+
+void mcrt_quantize_rgba8(const float* rgba, uint8_t* out, size_t n_pixels) {  // image_writer.cpp:18-22
+    for (size_t i = 0; i < n_pixels * 4; ++i) {
+        float v = rgba[i];
+        v = (v < 0.0f) ? 0.0f : ((1.0f < v) ? 1.0f : v);
+        out[i] = static_cast<uint8_t>(v * 255.0f + 0.5f);
+    }
+}
+
+int mcrt_render(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_rgba, mcrt_progress_fn progress,
+                void* user, int device) {
+    if (!desc || !cfg) return fail(MCRT_ERR_INVALID, "NULL argument");
+    if (!valid_frame(cfg)) return MCRT_OK;  // generateTiles → empty → untouched Image (tile_renderer.cpp:144-146)
+    if (!out_rgba) return fail(MCRT_ERR_INVALID, "out_rgba is NULL");
+    double t0 = now_ms();
+    mcrt_scene* s = nullptr;
+    int rc = mcrt_scene_create(desc, device, &s);
+    if (rc != MCRT_OK) return rc;
+    double t1 = now_ms();
+    const size_t npix = static_cast<size_t>(cfg->width) * cfg->height;
+    DeviceBuffer frame;
+    hipError_t e = frame.reserve(npix * 16);
+    if (e != hipSuccess) {
+        mcrt_scene_destroy(s);
+        return hip_fail(e, "frame allocation");
+    }
+    float kernel_ms = 0.0f, render_ms = 0.0f;
+    rc = mcrt_time_render_device(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, static_cast<float*>(frame.ptr), nullptr, 1,
+                                 &render_ms, &kernel_ms);
+    double t2 = now_ms();
+    if (rc == MCRT_OK) {
+        e = hipMemcpy(out_rgba, frame.ptr, npix * 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "frame download");
+    }
+    double t3 = now_ms();
+    frame.release();
+    mcrt_scene_destroy(s);
+    if (rc != MCRT_OK) return rc;
+    if (progress) {  // exactly totalTiles calls, done = 1..total (tile_renderer.cpp:168-172)
+        int total = mcrt_generate_tiles(cfg->width, cfg->height, cfg->tile_size, nullptr, 0);
+        for (int d = 1; d <= total; ++d) progress(d, total, user);
+    }
+    g_timings.flatten_ms = static_cast<float>(t1 - t0);
+    g_timings.h2d_ms = 0.0f;  // folded into flatten_ms (one 10-60 KB copy)
+    g_timings.kernel_ms = kernel_ms;
+    g_timings.d2h_ms = static_cast<float>(t3 - t2);
+    g_timings.total_ms = static_cast<float>(now_ms() - t0);
+    return MCRT_OK;
+}
+
+int mcrt_last_timings(mcrt_timings* out) {
+    if (!out) return MCRT_ERR_INVALID;
+    *out = g_timings;
+    return MCRT_OK;
+}
+
+// ---- probes -----------------------------------------------------------------------------------
+int mcrt_probe_intersect(mcrt_scene* s, const float* rays, int n, mcrt_hit* out) {
+    if (!s || !rays || !out || n < 0) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (n == 0) return MCRT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    DeviceBuffer d_rays, d_out;
+    HIP_TRY(d_rays.reserve(static_cast<size_t>(n) * 24));
+    HIP_TRY(d_out.reserve(static_cast<size_t>(n) * sizeof(mcrt_hit)));
+    HIP_TRY(hipMemcpy(d_rays.ptr, rays, static_cast<size_t>(n) * 24, hipMemcpyHostToDevice));
+    hipError_t e = launch_probe_intersect(static_cast<const uint8_t*>(s->blob.ptr), static_cast<float*>(d_rays.ptr), n,
+                                          static_cast<mcrt_hit*>(d_out.ptr), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out.ptr, static_cast<size_t>(n) * sizeof(mcrt_hit), hipMemcpyDeviceToHost);
+    d_rays.release();
+    d_out.release();
+    if (e != hipSuccess) return hip_fail(e, "probe_intersect");
+    return MCRT_OK;
+}
+
+int mcrt_probe_trace(mcrt_scene* s, const mcrt_config* cfg, const float* rays, int n, int depth, float* out_rgba) {
+    if (!s || !cfg || !rays || !out_rgba || n < 0) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (n == 0) return MCRT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    DeviceBuffer d_rays, d_out, d_rng, d_stack;
+    HIP_TRY(d_rays.reserve(static_cast<size_t>(n) * 24));
+    HIP_TRY(d_out.reserve(static_cast<size_t>(n) * 16));
+    bool long_rng = (cfg->soft_shadows && 2 * cfg->shadow_samples > 227) || (cfg->ao_enabled && 2 * cfg->ao_samples > 227);
+    if (long_rng) HIP_TRY(d_rng.reserve(static_cast<size_t>(n) * 624 * 4));
+    if (cfg->max_bounces > 16) HIP_TRY(d_stack.reserve(static_cast<size_t>(n) * cfg->max_bounces * 16));
+    HIP_TRY(hipMemcpy(d_rays.ptr, rays, static_cast<size_t>(n) * 24, hipMemcpyHostToDevice));
+    hipError_t e = launch_probe_trace(static_cast<const uint8_t*>(s->blob.ptr), *cfg, static_cast<float*>(d_rays.ptr), n,
+                                      depth, static_cast<float*>(d_out.ptr), static_cast<uint32_t*>(d_rng.ptr),
+                                      static_cast<float*>(d_stack.ptr), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_rgba, d_out.ptr, static_cast<size_t>(n) * 16, hipMemcpyDeviceToHost);
+    d_rays.release();
+    d_out.release();
+    d_rng.release();
+    d_stack.release();
+    if (e != hipSuccess) return hip_fail(e, "probe_trace");
+    return MCRT_OK;
+}
+
+int mcrt_probe_mt_uniform(int device, const uint32_t* seeds, int n_seeds, int n_draws, float* out) {
+    if (!seeds || !out || n_seeds < 0 || n_draws < 0) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (n_seeds == 0 || n_draws == 0) return MCRT_OK;
+    if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    DeviceBuffer d_seeds, d_out, d_store;
+    HIP_TRY(d_seeds.reserve(static_cast<size_t>(n_seeds) * 4));
+    HIP_TRY(d_out.reserve(static_cast<size_t>(n_seeds) * n_draws * 4));
+    if (n_draws > 227) HIP_TRY(d_store.reserve(static_cast<size_t>(n_seeds) * 624 * 4));
+    HIP_TRY(hipMemcpy(d_seeds.ptr, seeds, static_cast<size_t>(n_seeds) * 4, hipMemcpyHostToDevice));
+    hipError_t e = launch_probe_mt(static_cast<uint32_t*>(d_seeds.ptr), n_seeds, n_draws, static_cast<float*>(d_out.ptr),
+                                   static_cast<uint32_t*>(d_store.ptr), nullptr);
+    if (e == hipSuccess)
+        e = hipMemcpy(out, d_out.ptr, static_cast<size_t>(n_seeds) * n_draws * 4, hipMemcpyDeviceToHost);
+    d_seeds.release();
+    d_out.release();
+    d_store.release();
+    if (e != hipSuccess) return hip_fail(e, "probe_mt");
+    return MCRT_OK;
+}
+
+int mcrt_probe_detmath(int device, int op, const float* x, const float* y, size_t n, float* out) {
+    if (!x || !out || op < 0 || op > 2 || (op == 2 && !y)) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (n == 0) return MCRT_OK;
+    if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    DeviceBuffer dx, dy, dout;
+    HIP_TRY(dx.reserve(n * 4));
+    HIP_TRY(dout.reserve(n * 4));
+    HIP_TRY(hipMemcpy(dx.ptr, x, n * 4, hipMemcpyHostToDevice));
+    if (y) {
+        HIP_TRY(dy.reserve(n * 4));
+        HIP_TRY(hipMemcpy(dy.ptr, y, n * 4, hipMemcpyHostToDevice));
+    }
+    hipError_t e = launch_probe_detmath(op, static_cast<float*>(dx.ptr), static_cast<float*>(dy.ptr), n,
+                                        static_cast<float*>(dout.ptr), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout.ptr, n * 4, hipMemcpyDeviceToHost);
+    dx.release();
+    dy.release();
+    dout.release();
+    if (e != hipSuccess) return hip_fail(e, "probe_detmath");
+    return MCRT_OK;
+}
+
+int mcrt_probe_detmath_range(int device, int op, uint32_t lo_bits, uint32_t hi_bits, float y0, uint64_t* mismatches) {
+    if (!mismatches || op < 0 || op > 2 || hi_bits < lo_bits) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t total = static_cast<uint64_t>(hi_bits) - lo_bits + 1;
+    const uint64_t chunk = 1ull << 26;  // 64 Mi values = 256 MiB per pass
+    DeviceBuffer dout;
+    HIP_TRY(dout.reserve(chunk * 4));
+    std::vector<float> host(chunk);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    uint64_t bad = 0;
+    for (uint64_t off = 0; off < total; off += chunk) {
+        uint64_t cnt = total - off < chunk ? total - off : chunk;
+        uint32_t base = lo_bits + static_cast<uint32_t>(off);
+        hipError_t e = launch_probe_detmath_range(op, base, cnt, y0, static_cast<float*>(dout.ptr), nullptr);
+        if (e == hipSuccess) e = hipMemcpy(host.data(), dout.ptr, cnt * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            dout.release();
+            return hip_fail(e, "probe_detmath_range");
+        }
+        std::atomic<uint64_t> part{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&, t] {
+                uint64_t b = 0;
+                for (uint64_t i = t; i < cnt; i += nt) {
+                    float x = mcrt_u2f(base + static_cast<uint32_t>(i));
+                    float ref = op == 0 ? mcrt_sinf(x) : (op == 1 ? mcrt_cosf(x) : mcrt_powf(x, y0));
+                    uint32_t a = mcrt_f2u(ref), d = mcrt_f2u(host[i]);
+                    if (a != d && !(std::isnan(ref) && std::isnan(host[i]))) ++b;
+                }
+                part += b;
+            });
+        for (auto& th : pool) th.join();
+        bad += part.load();
+    }
+    dout.release();
+    *mismatches = bad;
+    return MCRT_OK;
+}
+
+}  // extern "C"
