@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the tile-render hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A *step* is one render of the BASELINE.json north-star frame (configs[1]: 1920x1080, 4 bounces,
+4 samples/pixel, one light, synthetic 64x64 skin with inner+outer layer, `RayTracer::Config`
+defaults otherwise) with the flattened scene already resident in HBM; the output is the float4
+framebuffer in HBM.  N > 1 (launched by torch.distributed.run, one process per GPU): the SAME frame
+is sharded by cyclic tile rows (rank r renders tile rows r, r+N, ...), each rank renders into a
+packed buffer and an RCCL gather over xGMI assembles the frame on rank 0 (strong scaling: the total
+work is fixed).  The gather of step k overlaps the render of step k+1.
+
+Rank 0 prints ONE JSON line: metric/value per BASELINE.json plus `roofline` (the trace kernel's
+algorithmic bytes, 16 B per output pixel, over its hipEvent-measured duration — this path is
+VALU-bound) and, at N = 1, `cpu_baseline` (the compiled reference, or the oracle
+port when oracle/_ref is absent, timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TLOPS = 78.6  # 157.3 TFLOP/s fp32 vector = 78.6 T non-FMA lane-ops/s
+
+WORKLOADS = {
+    # name: (width, height, bounces, spp, skin, pose)
+    "1080p_b4_spp4_S64": (1920, 1080, 4, 4, "S64", 0),  # BASELINE.json configs[1] — the metric's config
+    "4k_b8_spp16_S64": (3840, 2160, 8, 16, "S64", 0),  # configs[2]
+    "4k_b4_spp4_S64": (3840, 2160, 4, 4, "S64", 0),  # configs[3]
+    "8k_b8_spp64_S32": (7680, 4320, 8, 64, "S32", 0),  # configs[4] (single reference light)
+    "256_b1_spp1_S64": (256, 256, 1, 1, "S64", 0),  # configs[0]
+}
+
+
+def cpu_baseline(workload: str, frames: int = 3) -> dict:
+    """Times the reference's own std::thread TileRenderer (oracle/_ref) — or the oracle port — on the
+    host cores of this box, same scene/config, threadCount = 0 (all cores)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    import minecraftskin_raytracer_amd as M
+
+    w, h, b, spp, skin, pose = WORKLOADS[workload]
+    kind = "reference" if oraclelib.Reference.available() else "port"
+    lib = oraclelib.Reference() if kind == "reference" else oraclelib.Oracle()
+    sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
+    cfg = M.Config(width=w, height=h, maxBounces=b, samplesPerPixel=spp)
+    times = []
+    budget_s = 30.0
+    t_all = time.perf_counter()
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        lib.render(sd.ptr, cfg)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s:
+            break
+    med = statistics.median(times)
+    return {
+        "value": round(w * h / med / 1e6, 4),
+        "unit": "Mpixels/s",
+        "ms_per_frame": round(med * 1e3, 2),
+        "cores": os.cpu_count(),
+        "kind": kind,
+        "sample": f"{len(times)} full frame(s) of {workload}, median; threadCount=0 (std::thread pool over all host cores)",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="1080p_b4_spp4_S64", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    import minecraftskin_raytracer_amd as M
+    from minecraftskin_raytracer_amd import abi
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w, h, bounces, spp, skin, pose = WORKLOADS[args.workload]
+    cfg = M.Config(width=w, height=h, maxBounces=bounces, samplesPerPixel=spp)
+    sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
+    scene = M.DeviceScene(sd, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    frame = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    if world == 1:
+        def step(k: int) -> None:
+            scene.render_device(cfg, frame.data_ptr(), 0, 1, abi.LAYOUT_FRAME, stream)
+
+        def drain() -> None:
+            pass
+    else:
+        tiles_y = (h + cfg.tileSize - 1) // cfg.tileSize
+        max_rows = ((tiles_y + world - 1) // world) * cfg.tileSize  # padded so every rank sends the same count
+        packed = [torch.empty((max_rows, w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        gathered = [[torch.empty((max_rows, w, 4), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+        pending = []
+
+        def finish(k: int, work) -> None:
+            work.wait()
+            if rank == 0:
+                for r in range(world):
+                    M.unpack_rows_device(cfg, r, world, gathered[k & 1][r].data_ptr(), frame.data_ptr(), stream)
+
+        def step(k: int) -> None:
+            buf = packed[k & 1]
+            scene.render_device(cfg, buf.data_ptr(), rank, world, abi.LAYOUT_PACKED, stream)
+            work = dist.gather(buf, gathered[k & 1] if rank == 0 else None, dst=0, async_op=True)
+            if pending:
+                finish(*pending.pop())
+            pending.append((k, work))
+
+        def drain() -> None:
+            while pending:
+                finish(*pending.pop())
+
+    def sync() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only duration of the dominant (trace) kernel: hipEvents on the launch stream
+    first, stepn = (0, 1) if world == 1 else (rank, world)
+    layout = abi.LAYOUT_FRAME if world == 1 else abi.LAYOUT_PACKED
+    target = frame if world == 1 else packed[0]
+    render_ms, trace_ms = scene.time_render_device(cfg, target.data_ptr(), max(5, min(args.steps, 50)), first, stepn, layout, stream)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        mpix = w * h * args.steps / elapsed / 1e6
+        owned_rows = scene.owned_pixel_rows(cfg, first, stepn)
+        owned_px = min(owned_rows, h) * w if world > 1 else w * h
+        algo_bytes = 16.0 * owned_px  # 16 B written per output pixel, ~0 read
+        achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(args.workload)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpixels/s",
+            "value": round(mpix, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{w}x{h}, {bounces} bounces, {spp} spp, 1 light, synthetic 64x{64 if skin == 'S64' else 32} skin ({skin}), pose {pose}, soft shadows 8, tile 32",
+                "name": args.workload,
+                "parallelism": "single GPU" if world == 1 else f"cyclic tile rows over {world} GPUs + RCCL gather to rank 0 (overlapped)",
+            },
+            "kernel": {"trace_kernel_ms": round(trace_ms, 4), "render_ms_all_kernels": round(render_ms, 4)},
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "note": "algorithmic bytes = 16 B x output pixels per launch; the path is VALU-bound by construction (DESIGN.md)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.workload)
+            except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(line), flush=True)
+
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
