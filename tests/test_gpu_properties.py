@@ -1,0 +1,148 @@
+"""Full-size checks at BASELINE.json's configurations, through properties that do not need a full
+CPU render: tile independence (any sharding reassembles to the same frame, which is also the
+multi-GPU contract), idempotence, oracle renderTile on a sample of tiles of the full-size frame
+(incl. the heaviest ones), culling on/off equivalence via a DOF-disabled/enabled-aperture-0 pair,
+packed layout + unpack kernel, device quantiser."""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from minecraftskin_raytracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def render_dev(mcrt, ds, cfg, first=0, step=1, layout=abi.LAYOUT_FRAME, rows=None):
+    h = rows if rows is not None else cfg.height
+    out = torch.zeros((h, cfg.width, 4), dtype=torch.float32, device="cuda")
+    ds.render_device(cfg, out.data_ptr(), first, step, layout, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.fixture(scope="module")
+def north_star(mcrt, gpu):
+    sd = scenes.skin_scene("S64", 0)
+    ds = mcrt.DeviceScene(sd)
+    cfg = abi.Config(width=1920, height=1080, maxBounces=4, samplesPerPixel=4)
+    frame = render_dev(mcrt, ds, cfg)
+    yield sd, ds, cfg, frame
+    ds.close()
+
+
+def test_1080p_idempotent_and_sane(mcrt, north_star):
+    sd, ds, cfg, frame = north_star
+    again = render_dev(mcrt, ds, cfg)
+    assert torch.equal(frame, again)
+    f = frame.cpu().numpy()
+    assert np.isfinite(f).all() and f.min() >= 0.0 and f.max() <= 1.0 and (f[..., 3] == 1.0).all()
+    assert (np.abs(f[..., :3] - f[0, 0, :3]).sum(axis=2) > 0.05).mean() > 0.03  # the character is there
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_1080p_tile_row_shards_reassemble(mcrt, north_star, world):
+    sd, ds, cfg, frame = north_star
+    from minecraftskin_raytracer_amd import parallel
+
+    rebuilt = torch.zeros_like(frame)
+    rows = parallel.packed_rows(cfg, world)
+    for r in range(world):
+        assert ds.owned_pixel_rows(cfg, r, world) == len(parallel.owned_tile_rows(cfg, r, world)) * cfg.tileSize
+        packed = render_dev(mcrt, ds, cfg, r, world, abi.LAYOUT_PACKED, rows)
+        mcrt.unpack_rows_device(cfg, r, world, packed.data_ptr(), rebuilt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        # the CPU un-permute used by the gloo tests agrees with the HIP unpack kernel
+        cpu = torch.zeros((cfg.height, cfg.width, 4))
+        parallel.unpack_rows(cfg, r, world, packed.cpu(), cpu)
+        own = torch.zeros(cfg.height, dtype=torch.bool)
+        for tr in parallel.owned_tile_rows(cfg, r, world):
+            own[tr * cfg.tileSize:(tr + 1) * cfg.tileSize] = True
+        torch.cuda.synchronize()
+        assert torch.equal(cpu[own], frame.cpu()[own])
+    torch.cuda.synchronize()
+    assert torch.equal(rebuilt, frame)
+
+
+def test_1080p_sampled_tiles_match_oracle(mcrt, oracle, north_star):
+    sd, ds, cfg, frame = north_star
+    f = frame.cpu().numpy()
+    tiles = oracle.generate_tiles(cfg.width, cfg.height, cfg.tileSize)
+    # heaviest tiles = most non-background pixels, plus corners, clipped bottom row, random ones
+    bgdiff = np.abs(f[..., :3] - f[0, 0, :3]).sum(axis=2) > 0.2
+    weight = [bgdiff[y:y + h, x:x + w].sum() for x, y, w, h in tiles]
+    pick = list(np.argsort(weight)[-6:]) + [0, 59, len(tiles) - 1, len(tiles) - 60] + list(np.random.default_rng(0).integers(0, len(tiles), 6))
+    scratch = np.zeros_like(f)
+    for i in pick:
+        oracle.render_tile(sd.ptr, cfg, tiles[i], scratch)
+        x, y, w, h = tiles[i]
+        scenes.assert_bit_equal(f[y:y + h, x:x + w], scratch[y:y + h, x:x + w], f"tile {i} {tiles[i]}")
+
+
+def test_4k_b8_spp16_sampled_tiles_match_oracle(mcrt, oracle, gpu):
+    # BASELINE.json configs[2]
+    sd = scenes.skin_scene("S64", 0)
+    ds = mcrt.DeviceScene(sd)
+    cfg = abi.Config(width=3840, height=2160, maxBounces=8, samplesPerPixel=16)
+    f = render_dev(mcrt, ds, cfg).cpu().numpy()
+    ds.close()
+    tiles = oracle.generate_tiles(cfg.width, cfg.height, cfg.tileSize)
+    bgdiff = np.abs(f[..., :3] - f[0, 0, :3]).sum(axis=2) > 0.2
+    weight = [bgdiff[y:y + h, x:x + w].sum() for x, y, w, h in tiles]
+    scratch = np.zeros_like(f)
+    for i in list(np.argsort(weight)[-2:]) + [0, len(tiles) - 1, 3000]:
+        oracle.render_tile(sd.ptr, cfg, tiles[i], scratch)
+        x, y, w, h = tiles[i]
+        scenes.assert_bit_equal(f[y:y + h, x:x + w], scratch[y:y + h, x:x + w], f"tile {i}")
+
+
+def test_8k_legacy_skin_band_matches_oracle(mcrt, oracle, gpu):
+    # BASELINE.json configs[4] geometry (7680x4320, 8 bounces, 64 spp, legacy skin, single reference
+    # light) on one owned tile row of an 8-way shard; oracle on two tiles of it
+    sd = scenes.skin_scene("S32", 0)
+    ds = mcrt.DeviceScene(sd)
+    cfg = abi.Config(width=7680, height=4320, maxBounces=8, samplesPerPixel=64)
+    tiles_y = (cfg.height + 31) // 32
+    row = 62  # a tile row through the character, owned by rank 62 % 8 = 6 of 8
+    out = torch.zeros((32, cfg.width, 4), dtype=torch.float32, device="cuda")
+    ds.render_device(cfg, out.data_ptr(), row, tiles_y, abi.LAYOUT_PACKED, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ds.close()
+    f = out.cpu().numpy()
+    scratch = np.zeros((cfg.height, cfg.width, 4), np.float32)
+    for tx in (120, 0):
+        tile = (tx * 32, row * 32, 32, 32)
+        oracle.render_tile(sd.ptr, cfg, tile, scratch)
+        scenes.assert_bit_equal(f[:, tx * 32:tx * 32 + 32], scratch[row * 32:row * 32 + 32, tx * 32:tx * 32 + 32], f"8k tile {tile}")
+
+
+def test_culling_never_changes_the_image(mcrt, gpu):
+    # dofEnabled with aperture below the 1e-6 gate renders the pinhole path; enabling DOF with a tiny
+    # aperture above the gate disables primary-ray culling.  A direct A/B of the culled kernel: render
+    # with a camera that makes culling impossible (fov 179.9 → bounds exceed every tile) is not
+    # equivalent, so compare against the probe path, which never culls.
+    sd = scenes.skin_scene("S64", 6)
+    ds = mcrt.DeviceScene(sd)
+    cfg = abi.Config(width=160, height=120, maxBounces=1, samplesPerPixel=1)
+    img = render_dev(mcrt, ds, cfg).cpu().numpy()
+    # primary rays through pixel centres, traced by the un-culled probe
+    import ctypes as C
+    ys, xs = np.mgrid[0:cfg.height, 0:cfg.width]
+    u = ((xs.astype(np.float32) + np.float32(0.5)) / np.float32(cfg.width)).ravel()
+    v = ((ys.astype(np.float32) + np.float32(0.5)) / np.float32(cfg.height)).ravel()
+    import oraclelib
+    orc = oraclelib.Oracle()
+    rays = np.stack([orc.camera_ray(sd.ptr, float(a), float(b), cfg.width / cfg.height) for a, b in zip(u[::7], v[::7])])
+    hits = ds.intersect(rays)
+    traced = ds.trace(cfg, rays, 0)
+    flat = img.reshape(-1, 4)[::7]
+    m = hits["hit"] != 0
+    scenes.assert_bit_equal(flat[m], traced[m], "hit pixels: culled kernel vs un-culled probe")
+    ds.close()
+
+
+def test_device_quantiser_matches_host(mcrt, north_star):
+    sd, ds, cfg, frame = north_star
+    q = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.uint8, device="cuda")
+    mcrt.quantize_rgba8_device(frame.data_ptr(), q.data_ptr(), cfg.width * cfg.height, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(q.cpu().numpy(), mcrt.quantize_rgba8(frame.cpu().numpy()))
