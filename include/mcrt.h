@@ -130,6 +130,12 @@ typedef void (*mcrt_progress_fn)(int done, int total, void* user);
 int mcrt_render(const mcrt_scene_desc* scene, const mcrt_config* cfg, float* out_rgba,
                 mcrt_progress_fn progress, void* user, int device);
 
+/* TileRenderer::renderTile (tile_renderer.cpp:71-127): renders the one tile with row-major index
+ * tile_index (generateTiles order) and writes its pixels into frame_rgba, a full width*height
+ * float4 frame owned by the caller; all other pixels are left untouched. */
+int mcrt_render_tile(const mcrt_scene_desc* scene, const mcrt_config* cfg, int tile_index,
+                     float* frame_rgba, int device);
+
 /* ---- render: resident scene, device buffers (bench / multi-GPU path) --------------------- */
 typedef struct mcrt_scene mcrt_scene; /* flattened scene resident in HBM on one device */
 

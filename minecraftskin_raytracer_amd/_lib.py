@@ -15,7 +15,7 @@ _lib = None
 # every symbol include/mcrt.h declares
 EXPORTED_SYMBOLS = [
     "mcrt_config_init", "mcrt_generate_tiles", "mcrt_abi_version", "mcrt_device_count", "mcrt_last_error",
-    "mcrt_render", "mcrt_scene_create", "mcrt_scene_destroy", "mcrt_render_device", "mcrt_owned_pixel_rows",
+    "mcrt_render", "mcrt_render_tile", "mcrt_scene_create", "mcrt_scene_destroy", "mcrt_render_device", "mcrt_owned_pixel_rows",
     "mcrt_unpack_rows_device", "mcrt_quantize_rgba8_device", "mcrt_quantize_rgba8", "mcrt_last_timings",
     "mcrt_time_render_device", "mcrt_build_skin_scene", "mcrt_build_default_scene", "mcrt_builtin_pose",
     "mcrt_scene_desc_free", "mcrt_scene_flatten", "mcrt_probe_intersect", "mcrt_probe_trace",
@@ -45,6 +45,7 @@ def load():
         "mcrt_device_count": (C.c_int, []),
         "mcrt_last_error": (C.c_char_p, []),
         "mcrt_render": (C.c_int, [desc_p, cfg_p, f_p, abi.PROGRESS_FN, vp, C.c_int]),
+        "mcrt_render_tile": (C.c_int, [desc_p, cfg_p, C.c_int, f_p, C.c_int]),
         "mcrt_scene_create": (C.c_int, [desc_p, C.c_int, C.POINTER(vp)]),
         "mcrt_scene_destroy": (None, [vp]),
         "mcrt_render_device": (C.c_int, [vp, cfg_p, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -309,6 +310,36 @@ int mcrt_render(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_
     g_timings.kernel_ms = kernel_ms;
     g_timings.d2h_ms = static_cast<float>(t3 - t2);
     g_timings.total_ms = static_cast<float>(now_ms() - t0);
+    return MCRT_OK;
+}
+
+int mcrt_render_tile(const mcrt_scene_desc* desc, const mcrt_config* cfg, int tile_index, float* frame_rgba, int device) {
+    if (!desc || !cfg || !frame_rgba) return fail(MCRT_ERR_INVALID, "NULL argument");
+    if (!valid_frame(cfg)) return MCRT_OK;
+    Shard all = make_shard(*cfg, 0, 1);
+    if (tile_index < 0 || tile_index >= all.tiles_x * all.tiles_y) return fail(MCRT_ERR_INVALID, "tile index out of range");
+    const int row = tile_index / all.tiles_x, col = tile_index % all.tiles_x;
+    mcrt_scene* s = nullptr;
+    int rc = mcrt_scene_create(desc, device, &s);
+    if (rc != MCRT_OK) return rc;
+    // render the tile row that contains the tile (a shard of exactly one row), packed
+    const size_t row_floats = static_cast<size_t>(cfg->tile_size) * cfg->width * 4;
+    DeviceBuffer band;
+    std::vector<float> host(row_floats);
+    hipError_t e = band.reserve(row_floats * 4);
+    if (e == hipSuccess) {
+        rc = mcrt_render_device(s, cfg, row, all.tiles_y, MCRT_LAYOUT_PACKED, static_cast<float*>(band.ptr), nullptr);
+        if (rc == MCRT_OK) e = hipMemcpy(host.data(), band.ptr, row_floats * 4, hipMemcpyDeviceToHost);
+    }
+    band.release();
+    mcrt_scene_destroy(s);
+    if (e != hipSuccess) return hip_fail(e, "render_tile");
+    if (rc != MCRT_OK) return rc;
+    const int x0 = col * cfg->tile_size, y0 = row * cfg->tile_size;
+    const int tw = std::min(cfg->tile_size, cfg->width - x0), th = std::min(cfg->tile_size, cfg->height - y0);
+    for (int ly = 0; ly < th; ++ly)
+        std::memcpy(frame_rgba + 4 * (static_cast<size_t>(y0 + ly) * cfg->width + x0),
+                    host.data() + 4 * (static_cast<size_t>(ly) * cfg->width + x0), static_cast<size_t>(tw) * 16);
     return MCRT_OK;
 }
 
