@@ -8,7 +8,8 @@ import os
 from . import abi
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libmcrt.so")
+# MCRT_LIB selects another build of the SAME library (kernel tuning experiments); there is still no fallback
+LIB_PATH = os.environ.get("MCRT_LIB") or os.path.join(PKG, "libmcrt.so")
 
 _lib = None
 

@@ -56,6 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     ]
     if verbose:
         cmd += ["-Rpass-analysis=kernel-resource-usage"]
+    cmd += os.environ.get("MCRT_EXTRA_FLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", OUT, "-lpthread"]
     if verbose:

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -69,6 +70,16 @@ struct DeviceBuffer {
 
 bool valid_frame(const mcrt_config* c) { return c->width > 0 && c->height > 0 && c->tile_size > 0; }
 
+// work units the trace kernel aims for (tuning knob: MCRT_TARGET_UNITS)
+int target_units() {
+    static const int v = [] {
+        const char* e = std::getenv("MCRT_TARGET_UNITS");
+        int n = e ? std::atoi(e) : 0;
+        return n > 0 ? n : 8192;
+    }();
+    return v;
+}
+
 int draws_per_sample(const mcrt_config& c) {
     int spp = c.samples_per_pixel > 1 ? c.samples_per_pixel : 1;
     return (spp > 1 ? 2 : 0) + ((c.dof_enabled && c.aperture > 1e-6f) ? 2 : 0);
@@ -78,6 +89,8 @@ int draws_per_sample(const mcrt_config& c) {
 
 struct mcrt_scene {
     int device = 0;
+    uint32_t alpha_words = 0;
+    uint32_t n_meshes = 0;
     DeviceBuffer blob;
     DeviceBuffer tile_rng, hit_rng, deep_stack;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -94,7 +107,11 @@ int prepare(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layo
     p.layout = layout;
     p.out = d_out;
     p.draws_per_sample = draws_per_sample(*cfg);
-    p.grid_blocks = render_grid_blocks(p);
+    const bool fits = s->alpha_words <= static_cast<uint32_t>(kAlphaLdsWordsMax) && s->n_meshes * 6 <= static_cast<uint32_t>(kFaceLdsEntriesMax);
+    p.scene_in_lds = fits ? 1 : 0;
+    p.lds_alpha_words = fits ? static_cast<int>(s->alpha_words) : 0;
+    p.lds_face_entries = fits ? static_cast<int>(s->n_meshes * 6) : 0;
+    fill_launch_geometry(p, target_units());
     HIP_TRY(s->tile_rng.reserve(tile_rng_bytes(p)));
     HIP_TRY(s->hit_rng.reserve(hit_rng_bytes(p)));
     HIP_TRY(s->deep_stack.reserve(deep_stack_bytes(p)));
@@ -181,6 +198,8 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
     HIP_TRY(hipSetDevice(device));
     mcrt_scene* s = new mcrt_scene();
     s->device = device;
+    s->alpha_words = reinterpret_cast<const FlatHeader*>(b.data())->alpha_words;
+    s->n_meshes = reinterpret_cast<const FlatHeader*>(b.data())->n_meshes;
     hipError_t e = s->blob.reserve(b.size());
     if (e == hipSuccess) e = hipMemcpy(s->blob.ptr, b.data(), b.size(), hipMemcpyHostToDevice);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&s->ev[i]);
@@ -347,6 +366,12 @@ int mcrt_last_timings(mcrt_timings* out) {
     if (!out) return MCRT_ERR_INVALID;
     *out = g_timings;
     return MCRT_OK;
+}
+
+// Diagnostic builds only (-DMCRT_STAMPS): not part of include/mcrt.h, never used by the product.
+int mcrt_debug_phase_stamps(unsigned long long out[16], int reset) {
+    hipError_t e = read_phase_stamps(out, reset != 0);
+    return e == hipSuccess ? MCRT_OK : MCRT_ERR_HIP;
 }
 
 // ---- probes -----------------------------------------------------------------------------------

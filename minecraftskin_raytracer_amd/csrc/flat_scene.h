@@ -1,5 +1,5 @@
 // flat_scene.h — the scene as it lives in HBM: one contiguous blob
-//   [FlatHeader][FlatMesh x n_meshes][float4 texel pool]
+//   [FlatHeader][FlatMesh x n_meshes][float4 texel pool][2-bit alpha predicates per texel]
 // produced on the host by flatten.cpp from the reference-shaped mcrt_scene_desc and read by the
 // kernels through wave-uniform (scalar) loads.  Everything a ray needs that the reference
 // recomputes per ray from per-frame constants is evaluated once here, with the reference's own
@@ -67,7 +67,10 @@ struct FlatHeader {  // 192 bytes
     uint32_t mesh_offset;   // byte offset of FlatMesh[0] from the blob start
     uint32_t texel_offset;  // byte offset of the float4 texel pool
     uint32_t blob_bytes;
-    uint32_t pad2[13];
+    uint32_t alpha_offset;  // byte offset of the alpha-predicate words: 16 texels per uint32,
+                            // bit 2k = (alpha == 0.0f), bit 2k+1 = (alpha > 0.0f)  (intersection.cpp:311,349)
+    uint32_t alpha_words;
+    uint32_t pad2[11];
 };
 
 static_assert(sizeof(FlatMesh) == 160, "FlatMesh layout");

@@ -96,7 +96,9 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
 
     const size_t mesh_off = sizeof(FlatHeader);
     const size_t texel_off = mesh_off + sizeof(FlatMesh) * static_cast<size_t>(d->n_meshes);
-    const size_t total = texel_off + static_cast<size_t>(n_texels) * 16;
+    const size_t alpha_off = texel_off + static_cast<size_t>(n_texels) * 16;
+    const size_t alpha_words = static_cast<size_t>((n_texels + 15) / 16);
+    const size_t total = alpha_off + alpha_words * 4;
     blob.assign(total, 0);
     FlatHeader* h = reinterpret_cast<FlatHeader*>(blob.data());
     FlatMesh* fm = reinterpret_cast<FlatMesh*>(blob.data() + mesh_off);
@@ -106,6 +108,14 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
         if (tex_base[i] < 0) continue;
         const mcrt_texture& t = d->textures[i];
         std::memcpy(pool + 4 * tex_base[i], t.rgba, static_cast<size_t>(t.width) * t.height * 16);
+    }
+    // alpha predicates: the only two ways a texel's value decides hit/miss
+    // (texColor.a == 0.0f, intersection.cpp:311; backTexColor.a > 0.0f, :349)
+    uint32_t* abits = reinterpret_cast<uint32_t*>(blob.data() + alpha_off);
+    for (int64_t i = 0; i < n_texels; ++i) {
+        const float a = pool[4 * i + 3];
+        uint32_t bits = (a == 0.0f ? 1u : 0u) | (a > 0.0f ? 2u : 0u);
+        abits[i >> 4] |= bits << ((i & 15) * 2);
     }
 
     // ---- camera -----------------------------------------------------------------------------
@@ -133,6 +143,8 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
     h->mesh_offset = static_cast<uint32_t>(mesh_off);
     h->texel_offset = static_cast<uint32_t>(texel_off);
     h->blob_bytes = static_cast<uint32_t>(total);
+    h->alpha_offset = static_cast<uint32_t>(alpha_off);
+    h->alpha_words = static_cast<uint32_t>(alpha_words);
 
     // Culling is only offered for a well-conditioned pinhole camera: orthonormal basis, finite
     // positive tan(fov/2).  Anything else renders every mesh for every primary ray.

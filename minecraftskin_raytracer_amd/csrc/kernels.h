@@ -30,15 +30,26 @@ struct RenderParams {
     float* deep_stack;     // per-thread (max_bounces) x float4 slices when max_bounces > 16
     int draws_per_sample;  // 0, 2 or 4
     int grid_blocks;
+    int parts_per_tile;    // each tile is split into this many pixel-aligned work units
+    int lds_draw_floats;   // dynamic LDS: per-hit shadow draws of one sub-batch
+    int lds_alpha_words;   // dynamic LDS: alpha-predicate words staged per workgroup (0 = read from HBM)
+    int lds_face_entries;  // dynamic LDS: n_meshes * 6 face-table entries (0 = read FlatMesh from HBM)
+    int scene_in_lds;      // 1 when both tables fit the LDS budget (lean kernel variant allowed)
 };
 
 Shard make_shard(const mcrt_config& cfg, int first, int step);
+// diagnostic builds (-DMCRT_STAMPS) only: per-phase wave-cycle sums of the trace kernel
+hipError_t read_phase_stamps(unsigned long long out[16], bool reset);
 
 // workspace requirements (bytes) for a given config + shard
 size_t tile_rng_bytes(const RenderParams& p);
 size_t hit_rng_bytes(const RenderParams& p);
 size_t deep_stack_bytes(const RenderParams& p);
 int render_grid_blocks(const RenderParams& p);
+// chooses parts_per_tile, the dynamic-LDS split and the grid for p.cfg / p.shard
+void fill_launch_geometry(RenderParams& p, int target_units);
+constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
+constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
 
 // enqueue: tile-RNG seeding (if needed) + the trace kernel.  If ev_k0/ev_k1 are non-null they are
 // recorded on `stream` immediately around the trace kernel launch.

@@ -6,6 +6,15 @@
 // through wave-uniform indices, so the compiler keeps it in SGPRs (s_load) — the mesh loop is
 // uniform across the wave even when the rays are not.
 //
+// Legal restructurings used here (all leave every produced float bit-identical):
+//   * 1/d per axis is a function of the ray only → computed once per ray, not once per mesh;
+//   * a candidate whose entry distance cannot beat the current limit (closest-hit keeps strictly
+//     smaller t, intersection.cpp:415; shadow/AO rays ask "t < limit") is dropped before any UV or
+//     texel work;
+//   * hit/miss of a face depends on the texel only through (alpha == 0) and (alpha > 0): both
+//     predicates are precomputed per texel (2 bits, flatten.cpp) — the colour is fetched once, for
+//     the winning hit;
+//   * the hit normal is produced for the winning hit only.
 // Reference lines followed (under /root/reference/src) are named at each function.
 #ifndef MCRT_RT_CORE_H
 #define MCRT_RT_CORE_H
@@ -17,7 +26,10 @@
 #include "mcrt_detmath.h"
 
 #define DEV __device__ __forceinline__
-#define DEVNI __device__ __noinline__
+// Shared (non-inlined) routines: one copy of the mesh loop and of the libm kernels in the code
+// object.  The fully inlined trace kernel was 85 KB of code — larger than the 64 KB instruction
+// cache CUs share — and ran instruction-fetch bound.
+#define DEVCALL __device__ __noinline__
 
 namespace rt {
 
@@ -72,21 +84,47 @@ struct Hit {
     C4 tex;
 };
 
-// view of the flat blob
+// Views of the flat blob.  SceneView reads everything from HBM (probes, rare sequential paths).
+// SceneViewLds is what the trace kernel uses: the two tables that candidates index PER LANE — the
+// alpha predicates and the face → texture table — live in LDS and are typed as LDS pointers, so
+// the lookups compile to ds_read (a pointer that may be either LDS or global becomes a flat load).
+#define MCRT_LDS __attribute__((address_space(3)))
 struct SceneView {
+    static constexpr bool kLds = false;
     const FlatHeader* hdr;
     const FlatMesh* meshes;
     const float4* texels;
+    const uint32_t* abits;
     int n_meshes;
+    DEV SceneView global() const { return *this; }
+};
+struct SceneViewLds {
+    static constexpr bool kLds = true;
+    const FlatHeader* hdr;
+    const FlatMesh* meshes;
+    const float4* texels;
+    const uint32_t* abits_hbm;
+    const MCRT_LDS uint32_t* abits;  // 16 texels per word
+    const MCRT_LDS int* faces;       // per (mesh, face slot): {texel offset | MCRT_TEX_*, width, height, 0}
+    int n_meshes;
+    DEV SceneView global() const { return SceneView{hdr, meshes, texels, abits_hbm, n_meshes}; }
 };
 DEV SceneView view_of(const uint8_t* blob) {
     SceneView s;
     s.hdr = reinterpret_cast<const FlatHeader*>(blob);
     s.meshes = reinterpret_cast<const FlatMesh*>(blob + s.hdr->mesh_offset);
     s.texels = reinterpret_cast<const float4*>(blob + s.hdr->texel_offset);
+    s.abits = reinterpret_cast<const uint32_t*>(blob + s.hdr->alpha_offset);
     s.n_meshes = static_cast<int>(s.hdr->n_meshes);
     return s;
 }
+DEV SceneViewLds view_with_lds(const SceneView& g, const MCRT_LDS uint32_t* abits, const MCRT_LDS int* faces) {
+    return SceneViewLds{g.hdr, g.meshes, g.texels, g.abits, abits, faces, g.n_meshes};
+}
+
+DEVCALL float dev_sinf(float x) { return mcrt_sinf(x); }
+DEVCALL float dev_cosf(float x) { return mcrt_cosf(x); }
+DEVCALL float dev_powf(float x, float y) { return mcrt_powf(x, y); }
 
 // ---------------------------------------------------------------------------------------------
 // std::mt19937 — truncated, array-free form for short streams.
@@ -176,34 +214,73 @@ DEV uint32_t seed_cast(float f) {
     if (!(f > -0x1p63f && f < 0x1p63f)) return 0u;
     return static_cast<uint32_t>(static_cast<long long>(f));
 }
+DEV uint32_t shadow_seed(V3 p, int depth) {  // raytracer.cpp:110-112
+    return seed_cast(p.x * 12345.0f + p.y * 67890.0f + p.z * 11111.0f + static_cast<float>(depth) * 99999.0f);
+}
+DEV uint32_t ao_seed(V3 p) {  // raytracer.cpp:122-123
+    return seed_cast(p.x * 73856093.0f + p.y * 19349663.0f + p.z * 83492791.0f);
+}
 
 // ---------------------------------------------------------------------------------------------
 // intersection.cpp
 // ---------------------------------------------------------------------------------------------
-// TextureRegion::sample (texture_region.h:19-26) through the face table of the flat mesh
-DEV C4 face_texel(const SceneView& sc, const FlatMesh& m, int face, float u, float v) {
-    int off = m.tex_off[face];
-    if (off == MCRT_TEX_NULL) return C4{1.0f, 0.0f, 1.0f, 1.0f};  // :305
-    if (off == MCRT_TEX_EMPTY) return C4{0.0f, 0.0f, 0.0f, 1.0f};
-    int w = m.tex_w[face], h = m.tex_h[face];
+// A ray prepared for slab tests: the reciprocals of intersection.cpp:229 hoisted out of the mesh loop.
+struct RayQ {
+    V3 o, d, inv;
+    bool px, py, pz;  // |d| < 1e-8 on that axis (:222)
+};
+DEV RayQ prepare(const Ray& r) {
+    RayQ q;
+    q.o = r.o;
+    q.d = r.d;
+    q.px = __builtin_fabsf(r.d.x) < 1e-8f;
+    q.py = __builtin_fabsf(r.d.y) < 1e-8f;
+    q.pz = __builtin_fabsf(r.d.z) < 1e-8f;
+    q.inv.x = q.px ? 0.0f : 1.0f / r.d.x;
+    q.inv.y = q.py ? 0.0f : 1.0f / r.d.y;
+    q.inv.z = q.pz ? 0.0f : 1.0f / r.d.z;
+    return q;
+}
+
+// texel reference of a face at (u,v): pool index, or MCRT_TEX_NULL / MCRT_TEX_EMPTY
+// (TextureRegion::sample, texture_region.h:19-26)
+template <class SV>
+DEV int face_texel_index(const SV& sc, const FlatMesh& m, int mesh_index, int face, float u, float v) {
+    int off, w, h;
+    if constexpr (SV::kLds) {
+        const MCRT_LDS int* f = sc.faces + (mesh_index * 6 + face) * 4;
+        off = f[0], w = f[1], h = f[2];
+    } else {
+        off = m.tex_off[face], w = m.tex_w[face], h = m.tex_h[face];
+    }
+    if (off < 0) return off;
     int x = iclamp(static_cast<int>(u * w), 0, w - 1);
     int y = iclamp(static_cast<int>(v * h), 0, h - 1);
-    float4 t = sc.texels[off + y * w + x];
+    return off + y * w + x;
+}
+// bit0: alpha == 0.0f, bit1: alpha > 0.0f.  nullptr texture → magenta, empty → Color(): alpha 1.
+template <class SV>
+DEV uint32_t alpha_bits(const SV& sc, int texel) {
+    if (texel < 0) return 2u;
+    return (sc.abits[texel >> 4] >> ((texel & 15) * 2)) & 3u;
+}
+template <class SV>
+DEV C4 texel_color(const SV& sc, int texel) {
+    if (texel == MCRT_TEX_NULL) return C4{1.0f, 0.0f, 1.0f, 1.0f};  // intersection.cpp:305
+    if (texel < 0) return C4{0.0f, 0.0f, 0.0f, 1.0f};
+    float4 t = sc.texels[texel];
     return C4{t.x, t.y, t.z, t.w};
 }
 
-// determineFace :86-132 → face slot 0..5 and its normal
-DEV int face_slot(int axis, bool neg, V3& n) {
-    if (axis == 2) {
-        n = neg ? mk(0.0f, 0.0f, -1.0f) : mk(0.0f, 0.0f, 1.0f);
-        return neg ? 0 : 1;
-    }
-    if (axis == 0) {
-        n = neg ? mk(-1.0f, 0.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
-        return neg ? 3 : 2;
-    }
-    n = neg ? mk(0.0f, -1.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
+// determineFace :86-132 → face slot 0..5
+DEV int face_slot(int axis, bool neg) {
+    if (axis == 2) return neg ? 0 : 1;
+    if (axis == 0) return neg ? 3 : 2;
     return neg ? 5 : 4;
+}
+DEV V3 face_normal(int axis, bool neg) {
+    float s = neg ? -1.0f : 1.0f;
+    return mk(axis == 0 ? s : 0.0f, axis == 1 ? s : 0.0f, axis == 2 ? s : 0.0f);
 }
 
 // computeFaceUV :136-196
@@ -235,112 +312,51 @@ DEV void face_uv(V3 hp, V3 lo, V3 hi, int axis, bool neg, float& u, float& v) {
 // Slab state of one ray against one box (:221-250 plus the exit-face scan :268-285 ≡ :323-335,
 // which is the same function of (ray, box) in both places).
 struct Slab {
-    bool overlap;  // survived the slab loop
+    bool overlap;
     float tmin, tmax;
     int in_axis, out_axis;
     bool in_neg, out_neg;
 };
 
-DEV Slab slab_test(const Ray& r, V3 lo, V3 hi) {
+DEV void slab_axis(Slab& s, float& best_exit, int i, bool par, float o, float inv, float l, float h) {
+    if (par) {
+        if (o < l || o > h) s.overlap = false;
+        return;
+    }
+    float t0 = (l - o) * inv;
+    float t1 = (h - o) * inv;
+    bool swapped = t0 > t1;
+    float tn = swapped ? t1 : t0;
+    float tf = swapped ? t0 : t1;
+    if (tn > s.tmin) {
+        s.tmin = tn;
+        s.in_axis = i;
+        s.in_neg = !swapped;
+    }
+    s.tmax = smin(s.tmax, tf);
+    // the reference tests this inside the loop; tmin only grows and tmax only shrinks, so a failure
+    // at any iteration is equivalent to failing here and staying failed
+    if (s.tmin > s.tmax || s.tmax < 0.0f) s.overlap = false;
+    if (tf < best_exit) {
+        best_exit = tf;
+        s.out_axis = i;
+        s.out_neg = swapped;
+    }
+}
+DEV Slab slab_test(const RayQ& r, V3 lo, V3 hi) {
     Slab s;
     s.overlap = true;
     s.tmin = -kFltMax;
     s.tmax = kFltMax;
     s.in_axis = 0;
     s.in_neg = false;
-    float best_exit = kFltMax;
     s.out_axis = 0;
     s.out_neg = false;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float d = comp(r.d, i), o = comp(r.o, i), l = comp(lo, i), h = comp(hi, i);
-        if (__builtin_fabsf(d) < 1e-8f) {
-            if (o < l || o > h) s.overlap = false;
-        } else {
-            float inv = 1.0f / d;
-            float t0 = (l - o) * inv;
-            float t1 = (h - o) * inv;
-            bool swapped = t0 > t1;
-            float tn = swapped ? t1 : t0;  // near
-            float tf = swapped ? t0 : t1;  // far
-            if (tn > s.tmin) {
-                s.tmin = tn;
-                s.in_axis = i;
-                s.in_neg = !swapped;
-            }
-            s.tmax = smin(s.tmax, tf);
-            // the reference tests this inside the loop; tmin only grows and tmax only shrinks, so
-            // a failing test at any iteration is equivalent to failing here and staying failed
-            if (s.tmin > s.tmax || s.tmax < 0.0f) s.overlap = false;
-            if (tf < best_exit) {
-                best_exit = tf;
-                s.out_axis = i;
-                s.out_neg = swapped;
-            }
-        }
-    }
+    float best_exit = kFltMax;
+    slab_axis(s, best_exit, 0, r.px, r.o.x, r.inv.x, lo.x, hi.x);
+    slab_axis(s, best_exit, 1, r.py, r.o.y, r.inv.y, lo.y, hi.y);
+    slab_axis(s, best_exit, 2, r.pz, r.o.z, r.inv.z, lo.z, hi.z);
     return s;
-}
-
-// intersectAABB :200-371 in the mesh's own space.  `t_limit`: candidates that cannot beat it are
-// dropped before the texture fetch (closest-hit keeps only strictly smaller t, :415).
-DEV Hit hit_box(const SceneView& sc, const FlatMesh& m, const Ray& r) {
-    Hit res;
-    res.hit = false;
-    res.outer = false;
-    res.t = 0.0f;
-    res.p = mk(0, 0, 0);
-    res.n = mk(0, 0, 0);
-    res.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
-    if (m.flags & MESH_EMPTY) return res;
-    V3 lo = ld3(m.lo), hi = ld3(m.hi);
-    Slab s = slab_test(r, lo, hi);
-    if (!s.overlap) return res;
-
-    float tHit = s.tmin;
-    int axis = s.in_axis;
-    bool neg = s.in_neg;
-    if (tHit < 0.0f) {  // origin inside: exit face
-        tHit = s.tmax;
-        if (tHit < 0.0f) return res;
-        axis = s.out_axis;
-        neg = s.out_neg;
-    }
-    V3 hp = r.o + r.d * tHit;
-    V3 n;
-    int face = face_slot(axis, neg, n);
-    float u, v;
-    face_uv(hp, lo, hi, axis, neg, u, v);
-    C4 tc = face_texel(sc, m, face, u, v);
-    const bool outer = (m.flags & MESH_OUTER) != 0;
-
-    if (tc.a == 0.0f) {  // :311-361
-        if (!outer) return res;
-        if (s.tmax > tHit) {
-            V3 bp = r.o + r.d * s.tmax;
-            V3 bn;
-            int bface = face_slot(s.out_axis, s.out_neg, bn);
-            float bu, bv;
-            face_uv(bp, lo, hi, s.out_axis, s.out_neg, bu, bv);
-            C4 bc = face_texel(sc, m, bface, bu, bv);
-            if (bc.a > 0.0f) {
-                res.hit = true;
-                res.t = s.tmax;
-                res.p = bp;
-                res.n = bn * -1.0f;
-                res.tex = bc;
-                res.outer = true;
-            }
-        }
-        return res;
-    }
-    res.hit = true;
-    res.t = tHit;
-    res.p = hp;
-    res.n = n;
-    res.tex = tc;
-    res.outer = outer;
-    return res;
 }
 
 // rotatePoint :12-37 with the trig hoisted to the flat mesh
@@ -360,60 +376,164 @@ DEV V3 spin(V3 p, V3 pivot, bool ax, float cx, float sx, bool az, float cz, floa
     }
     return q + pivot;
 }
+DEV V3 to_world(const FlatMesh& m, V3 p, V3 pivot) {
+    return spin(p, pivot, (m.flags & MESH_APPLY_X) != 0, m.fwd_x_cos, m.fwd_x_sin, (m.flags & MESH_APPLY_Z) != 0,
+                m.fwd_z_cos, m.fwd_z_sin);
+}
 
-// intersectMesh :373-406
-DEV Hit hit_mesh(const SceneView& sc, const FlatMesh& m, const Ray& r) {
-    if (!(m.flags & MESH_ROTATED)) return hit_box(sc, m, r);
-    const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
-    V3 pivot = ld3(m.pivot);
-    V3 zero = mk(0.0f, 0.0f, 0.0f);
-    V3 lo = spin(r.o, pivot, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
-    lo = spin(lo, pivot, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
-    V3 ld = spin(r.d, zero, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
-    ld = spin(ld, zero, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
-    Ray local{lo, normalize(ld)};
-    Hit h = hit_box(sc, m, local);
-    if (h.hit) {
-        h.p = spin(h.p, pivot, ax, m.fwd_x_cos, m.fwd_x_sin, az, m.fwd_z_cos, m.fwd_z_sin);
-        h.n = normalize(spin(h.n, zero, ax, m.fwd_x_cos, m.fwd_x_sin, az, m.fwd_z_cos, m.fwd_z_sin));
-        h.t = dot(h.p - r.o, r.d);
+// What a mesh contributes to a ray query: intersectMesh (:373-406) over intersectAABB (:200-371)
+// without the texel colour and without the normal vector.
+struct Cand {
+    float t;    // HitResult::t (world-space for posed meshes, :402)
+    V3 p;       // HitResult::point (world space)
+    int texel;  // texel reference of the face that was hit
+    int axis;   // face: axis / min-side, in the mesh's local frame
+    bool neg;
+    bool back;  // outer-layer exit face: normal flipped, isOuterLayer forced (:349-357)
+};
+
+// Returns true when the mesh yields a hit with t < t_limit.
+template <class SV>
+DEV bool mesh_candidate(const SV& sc, const FlatMesh& m, int mesh_index, const RayQ& world, float t_limit, Cand& c) {
+    if (m.flags & MESH_EMPTY) return false;
+    const bool rotated = (m.flags & MESH_ROTATED) != 0;
+    const V3 lo = ld3(m.lo), hi = ld3(m.hi);
+    const V3 pivot = ld3(m.pivot);
+    RayQ local = world;
+    if (rotated) {
+        const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
+        const V3 zero = mk(0.0f, 0.0f, 0.0f);
+        V3 o = spin(world.o, pivot, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
+        o = spin(o, pivot, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
+        V3 d = spin(world.d, zero, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
+        d = spin(d, zero, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
+        local = prepare(Ray{o, normalize(d)});
     }
-    return h;
+    const Slab s = slab_test(local, lo, hi);
+    if (!s.overlap) return false;
+
+    float tHit = s.tmin;
+    int axis = s.in_axis;
+    bool neg = s.in_neg;
+    if (tHit < 0.0f) {  // origin inside the box: leave through the exit face (:255-288)
+        tHit = s.tmax;
+        if (tHit < 0.0f) return false;
+        axis = s.out_axis;
+        neg = s.out_neg;
+    }
+    // un-posed meshes: local t IS the reported t, and the exit face is never nearer than the entry
+    if (!rotated && !(tHit < t_limit)) return false;
+
+    V3 hp = local.o + local.d * tHit;
+    float t_front = tHit;
+    V3 p_front = hp;
+    if (rotated) {
+        p_front = to_world(m, hp, pivot);
+        t_front = dot(p_front - world.o, world.d);  // :402
+    }
+    float u, v;
+    face_uv(hp, lo, hi, axis, neg, u, v);
+    int texel = face_texel_index(sc, m, mesh_index, face_slot(axis, neg), u, v);
+    if (!(alpha_bits(sc, texel) & 1u)) {  // texColor.a != 0 → ordinary hit
+        if (!(t_front < t_limit)) return false;
+        c.t = t_front;
+        c.p = p_front;
+        c.texel = texel;
+        c.axis = axis;
+        c.neg = neg;
+        c.back = false;
+        return true;
+    }
+    // transparent texel (:311-361): inner layer → miss; outer layer → try the exit face
+    if (!(m.flags & MESH_OUTER)) return false;
+    if (!(s.tmax > tHit)) return false;
+    V3 bp = local.o + local.d * s.tmax;
+    float bu, bv;
+    face_uv(bp, lo, hi, s.out_axis, s.out_neg, bu, bv);
+    int btexel = face_texel_index(sc, m, mesh_index, face_slot(s.out_axis, s.out_neg), bu, bv);
+    if (!(alpha_bits(sc, btexel) & 2u)) return false;  // backTexColor.a > 0
+    float t_back = s.tmax;
+    V3 p_back = bp;
+    if (rotated) {
+        p_back = to_world(m, bp, pivot);
+        t_back = dot(p_back - world.o, world.d);
+    }
+    if (!(t_back < t_limit)) return false;
+    c.t = t_back;
+    c.p = p_back;
+    c.texel = btexel;
+    c.axis = s.out_axis;
+    c.neg = s.out_neg;
+    c.back = true;
+    return true;
 }
 
 // intersectScene :408-421.  mesh_mask: bit i set → mesh i is tested (primary-ray culling; all
 // ones for secondary rays).  Meshes beyond bit 63 are always tested.
-DEV Hit hit_scene(const SceneView& sc, const Ray& r, uint64_t mesh_mask) {
-    Hit best;
-    best.hit = false;
-    best.outer = false;
+template <class SV>
+DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
+    const RayQ q = prepare(r);
+    Cand best;
     best.t = kFltMax;
     best.p = mk(0, 0, 0);
-    best.n = mk(0, 0, 0);
-    best.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
+    best.texel = MCRT_TEX_EMPTY;
+    best.axis = 0;
+    best.neg = false;
+    best.back = false;
+    int best_mesh = -1;
     for (int i = 0; i < sc.n_meshes; ++i) {
         if (i < 64 && !((mesh_mask >> i) & 1ull)) continue;
-        Hit h = hit_mesh(sc, sc.meshes[i], r);
-        if (h.hit && h.t < best.t) best = h;
+        Cand c;
+        if (mesh_candidate(sc, sc.meshes[i], i, q, best.t, c)) {  // strictly smaller t wins, first mesh on ties
+            best = c;
+            best_mesh = i;
+        }
     }
-    return best;
+    Hit h;
+    h.hit = best_mesh >= 0;
+    h.outer = false;
+    h.t = h.hit ? best.t : kFltMax;
+    h.p = best.p;
+    h.n = mk(0, 0, 0);
+    h.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
+    if (h.hit) {
+        const FlatMesh& m = sc.meshes[best_mesh];
+        V3 n = face_normal(best.axis, best.neg);
+        if (best.back) n = n * -1.0f;  // :354
+        if (m.flags & MESH_ROTATED) {  // :400
+            n = normalize(spin(n, mk(0.0f, 0.0f, 0.0f), (m.flags & MESH_APPLY_X) != 0, m.fwd_x_cos, m.fwd_x_sin,
+                               (m.flags & MESH_APPLY_Z) != 0, m.fwd_z_cos, m.fwd_z_sin));
+        }
+        h.n = n;
+        h.tex = texel_color(sc, best.texel);
+        h.outer = best.back || (m.flags & MESH_OUTER) != 0;
+    }
+    return h;
 }
 
 // "hit && t < limit" over the scene without keeping the hit: isInShadow :25 and computeAO :72.
-// The reference finds the closest hit first; min t < limit ⇔ some t < limit, so the scan may
-// stop at the first mesh that qualifies.
-DEV bool any_hit_before(const SceneView& sc, const Ray& r, float limit) {
+// The reference finds the closest hit first; min t < limit ⇔ some t < limit, so the scan stops at
+// the first mesh that qualifies.
+template <class SV>
+DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
+    const RayQ q = prepare(r);
     for (int i = 0; i < sc.n_meshes; ++i) {
-        Hit h = hit_mesh(sc, sc.meshes[i], r);
-        if (h.hit && h.t < limit) return true;
+        Cand c;
+        if (mesh_candidate(sc, sc.meshes[i], i, q, limit, c)) return true;
     }
     return false;
 }
 
+// shared copy for the rare sequential paths (AO, very long shadow streams, probes)
+DEVCALL bool any_hit_call(SceneView sc, Ray r, float limit) { return any_hit_inline(sc, r, limit); }
+template <class SV>
+DEV bool any_hit_before(const SV& sc, const Ray& r, float limit) { return any_hit_call(sc.global(), r, limit); }
+
 // ---------------------------------------------------------------------------------------------
 // shading.cpp
 // ---------------------------------------------------------------------------------------------
-DEV bool in_shadow(const SceneView& sc, V3 point, V3 normal, V3 light) {  // :14-26
+template <class SV>
+DEV bool in_shadow(const SV& sc, V3 point, V3 normal, V3 light) {  // :14-26
     V3 origin = point + normal * 1e-3f;
     V3 to = light - origin;
     float dist = length(to);
@@ -422,30 +542,66 @@ DEV bool in_shadow(const SceneView& sc, V3 point, V3 normal, V3 light) {  // :14
     return any_hit_before(sc, r, dist);
 }
 
-DEV float soft_shadow(const SceneView& sc, V3 point, V3 normal, int samples, uint32_t seed,
-                      uint32_t* mt_storage) {  // :28-60
+// How the shadow term of a hit is obtained (raytracer.cpp:107-115 + shading.cpp:28-41,:76-80):
+enum ShadowMode : int {
+    SHADOW_SOFT = 0,       // softShadows && shadowSamples > 1 && radius >= 1e-4: disk samples, raw normal
+    SHADOW_SOFT_POINT = 1, // softShadows && shadowSamples > 1 but radius < 1e-4: one ray, raw normal
+    SHADOW_HARD = 2,       // otherwise: shade()'s own test, normalised normal
+};
+template <class SV>
+DEV int shadow_mode(const SV& sc, const mcrt_config& cfg) {
+    if (cfg.soft_shadows && cfg.shadow_samples > 1) return (sc.hdr->light_radius < 1e-4f) ? SHADOW_SOFT_POINT : SHADOW_SOFT;
+    return SHADOW_HARD;
+}
+
+// one stratified-disk light sample position (shading.cpp:35-53)
+template <class SV>
+DEV V3 light_sample_position(const SV& sc, V3 point, float d0, float d1) {
     V3 lpos = ld3(sc.hdr->light_pos);
-    float radius = sc.hdr->light_radius;
-    if (samples <= 1 || radius < 1e-4f) return in_shadow(sc, point, normal, lpos) ? 0.0f : 1.0f;
     V3 toPoint = normalize(point - lpos);
     V3 tangent = (__builtin_fabsf(toPoint.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), toPoint))
                                                      : normalize(cross(mk(0, 1, 0), toPoint));
     V3 bitangent = cross(toPoint, tangent);
+    float angle = kTwoPi * d0;
+    float rr = sc.hdr->light_radius * __builtin_sqrtf(d1);
+    V3 off = tangent * (rr * dev_cosf(angle)) + bitangent * (rr * dev_sinf(angle));
+    return lpos + off;
+}
+template <class SV>
+DEV bool light_sample_visible(const SV& sc, V3 point, V3 normal, float d0, float d1) {
+    return !in_shadow(sc, point, normal, light_sample_position(sc, point, d0, d1));
+}
+// isInShadow (:14-26) with the scene scan inlined at the call site (trace kernel phase C)
+template <class SV>
+DEV bool in_shadow_inline(const SV& sc, V3 point, V3 normal, V3 light) {
+    V3 origin = point + normal * 1e-3f;
+    V3 to = light - origin;
+    float dist = length(to);
+    if (dist < 1e-6f) return false;
+    Ray r{origin, vdiv(to, dist)};
+    return any_hit_inline(sc, r, dist);
+}
+
+// computeSoftShadow :28-60, sequential form (probes; the trace kernel spreads the samples over lanes)
+template <class SV>
+DEV float soft_shadow(const SV& sc, V3 point, V3 normal, int samples, uint32_t seed, uint32_t* mt_storage) {
+    V3 lpos = ld3(sc.hdr->light_pos);
+    if (samples <= 1 || sc.hdr->light_radius < 1e-4f) return in_shadow(sc, point, normal, lpos) ? 0.0f : 1.0f;
     HitRng rng;
     rng.seed(seed, 2 * samples, mt_storage);
     int lit = 0;
     for (int i = 0; i < samples; ++i) {
-        float angle = kTwoPi * rng.uniform();
-        float rr = radius * __builtin_sqrtf(rng.uniform());
-        V3 off = tangent * (rr * mcrt_cosf(angle)) + bitangent * (rr * mcrt_sinf(angle));
-        if (!in_shadow(sc, point, normal, lpos + off)) ++lit;
+        float d0 = rng.uniform();
+        float d1 = rng.uniform();
+        if (light_sample_visible(sc, point, normal, d0, d1)) ++lit;
     }
     return static_cast<float>(lit) / static_cast<float>(samples);
 }
 
 // shade :62-96 with ShadingParams{} (kd .75, ks .15, ambient .20, shininess 16 — shading.h:9-14;
-// renderTile always passes the defaults, tile_renderer.cpp:106-107)
-DEV C4 shade(const SceneView& sc, const Hit& hit, V3 viewDir, float shadowFactor) {
+// renderTile always passes the defaults, tile_renderer.cpp:106-107) and the visibility term given.
+template <class SV>
+DEV C4 shade(const SV& sc, const Hit& hit, V3 viewDir, float vis) {
     const float kd = 0.75f, ks = 0.15f, ambient = 0.20f, shininess = 16.0f;
     C4 tex = hit.tex;
     V3 lpos = ld3(sc.hdr->light_pos);
@@ -453,13 +609,11 @@ DEV C4 shade(const SceneView& sc, const Hit& hit, V3 viewDir, float shadowFactor
     V3 L = normalize(lpos - hit.p);
     V3 N = normalize(hit.n);
     V3 V = normalize(viewDir);
-    float vis = shadowFactor;
-    if (vis < 0.0f) vis = in_shadow(sc, hit.p, N, lpos) ? 0.0f : 1.0f;
     float ndl = smax(0.0f, dot(N, L));
     float kdiff = kd * ndl * vis;
     V3 H = normalize(L + V);
     float ndh = smax(0.0f, dot(N, H));
-    float kspec = ks * mcrt_powf(ndh, shininess) * vis;
+    float kspec = ks * dev_powf(ndh, shininess) * vis;
     C4 out;
     out.r = tex.r * ambient + tex.r * lc[0] * kdiff + lc[0] * kspec;
     out.g = tex.g * ambient + tex.g * lc[1] * kdiff + lc[1] * kspec;
@@ -471,7 +625,8 @@ DEV C4 shade(const SceneView& sc, const Hit& hit, V3 viewDir, float shadowFactor
 // ---------------------------------------------------------------------------------------------
 // raytracer.cpp
 // ---------------------------------------------------------------------------------------------
-DEV C4 background(const SceneView& sc, const mcrt_config& cfg, float u, float v) {  // :16-34
+template <class SV>
+DEV C4 background(const SV& sc, const mcrt_config& cfg, float u, float v) {  // :16-34
     if (cfg.gradient_bg) {
         float cx = u - 0.5f, cy = v - 0.5f;
         float dist = __builtin_sqrtf(cx * cx + cy * cy) * 2.0f * cfg.gradient_scale;
@@ -488,7 +643,8 @@ DEV C4 background(const SceneView& sc, const mcrt_config& cfg, float u, float v)
     return C4{b[0], b[1], b[2], b[3]};
 }
 
-DEV float ambient_occlusion(const SceneView& sc, V3 point, V3 normal, int samples, float radius,
+template <class SV>
+DEV float ambient_occlusion(const SV& sc, V3 point, V3 normal, int samples, float radius,
                             uint32_t seed, uint32_t* mt_storage) {  // :38-78
     V3 N = normalize(normal);
     V3 T = (__builtin_fabsf(N.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), N)) : normalize(cross(mk(0, 1, 0), N));
@@ -502,7 +658,7 @@ DEV float ambient_occlusion(const SceneView& sc, V3 point, V3 normal, int sample
         float sinT = __builtin_sqrtf(1.0f - r1);
         float cosT = __builtin_sqrtf(r1);
         float phi = kTwoPi * r2;
-        V3 local = mk(sinT * mcrt_cosf(phi), cosT, sinT * mcrt_sinf(phi));
+        V3 local = mk(sinT * dev_cosf(phi), cosT, sinT * dev_sinf(phi));
         V3 world = normalize(T * local.x + N * local.y + B * local.z);
         Ray r{point + N * 1e-3f, world};
         if (any_hit_before(sc, r, radius)) ++occluded;
@@ -510,26 +666,30 @@ DEV float ambient_occlusion(const SceneView& sc, V3 point, V3 normal, int sample
     return 1.0f - static_cast<float>(occluded) / static_cast<float>(samples);
 }
 
-// Shading of one hit level: everything traceRay does at a hit before recursing (:104-131).
-DEV C4 shade_level(const SceneView& sc, const mcrt_config& cfg, const Ray& ray, const Hit& hit,
-                   int depth, uint32_t* mt_storage) {
-    V3 view = normalize(ray.o - hit.p);
-    float shadowFactor = -1.0f;
-    if (cfg.soft_shadows && cfg.shadow_samples > 1) {
-        uint32_t seed = seed_cast(hit.p.x * 12345.0f + hit.p.y * 67890.0f + hit.p.z * 11111.0f +
-                                  static_cast<float>(depth) * 99999.0f);
-        shadowFactor = soft_shadow(sc, hit.p, hit.n, cfg.shadow_samples, seed, mt_storage);
-    }
-    C4 c = shade(sc, hit, view, shadowFactor);
+// colour of a hit level once its visibility term is known: shade + AO (raytracer.cpp:117-131)
+template <class SV>
+DEV C4 level_color(const SV& sc, const mcrt_config& cfg, V3 ray_origin, const Hit& hit, int depth, float vis,
+                   uint32_t* mt_storage) {
+    V3 view = normalize(ray_origin - hit.p);
+    C4 c = shade(sc, hit, view, vis);
     if (cfg.ao_enabled && depth == 0) {
-        uint32_t seed = seed_cast(hit.p.x * 73856093.0f + hit.p.y * 19349663.0f + hit.p.z * 83492791.0f);
-        float ao = ambient_occlusion(sc, hit.p, hit.n, cfg.ao_samples, cfg.ao_radius, seed, mt_storage);
+        float ao = ambient_occlusion(sc, hit.p, hit.n, cfg.ao_samples, cfg.ao_radius, ao_seed(hit.p), mt_storage);
         float k = 1.0f - cfg.ao_intensity * (1.0f - ao);
         c.r *= k;
         c.g *= k;
         c.b *= k;
     }
     return c;
+}
+
+// visibility term of a hit, sequential form
+template <class SV>
+DEV float hit_visibility(const SV& sc, const mcrt_config& cfg, const Hit& hit, int depth, uint32_t* mt_storage) {
+    const int mode = shadow_mode(sc, cfg);
+    V3 lpos = ld3(sc.hdr->light_pos);
+    if (mode == SHADOW_SOFT) return soft_shadow(sc, hit.p, hit.n, cfg.shadow_samples, shadow_seed(hit.p, depth), mt_storage);
+    if (mode == SHADOW_SOFT_POINT) return in_shadow(sc, hit.p, hit.n, lpos) ? 0.0f : 1.0f;
+    return in_shadow(sc, hit.p, normalize(hit.n), lpos) ? 0.0f : 1.0f;
 }
 
 // reflection ray of a hit (:133-139)
@@ -552,20 +712,22 @@ DEV C4 fold_reflection(C4 c, C4 deeper) {
     return clamp4(o);
 }
 
-constexpr int kMaxStack = 16;  // levels kept in registers/LDS-free scratch; deeper → global stack
+constexpr int kMaxStack = 16;  // levels kept in per-lane scratch; deeper → per-thread HBM slice
 
 // RayTracer::traceRay (:82-148) for a ray whose depth-`depth` hit is already known, as a loop:
-// walk down while rays keep hitting (level colours pushed), then fold back to front.
-// `stack` is caller-provided storage for (max_bounces + 1) C4 entries.
-DEV C4 trace_from_hit(const SceneView& sc, const mcrt_config& cfg, Ray ray, Hit hit, int depth,
+// walk down while rays keep hitting (level colours pushed), then fold back to front.  Sequential
+// per-lane form (probes); the trace kernel runs the same steps as workgroup phases.
+template <class SV>
+DEV C4 trace_from_hit(const SV& sc, const mcrt_config& cfg, Ray ray, Hit hit, int depth,
                       C4* stack, uint32_t* mt_storage) {
     const float* b = sc.hdr->background;
     const C4 flat_bg{b[0], b[1], b[2], b[3]};
     const int max_b = cfg.max_bounces;
     int top = 0;
-    C4 tail;  // colour returned by the level below the last pushed one
+    C4 tail;
     for (;;) {
-        C4 c = shade_level(sc, cfg, ray, hit, depth, mt_storage);
+        float vis = hit_visibility(sc, cfg, hit, depth, mt_storage);
+        C4 c = level_color(sc, cfg, ray.o, hit, depth, vis, mt_storage);
         if (depth >= max_b) {  // no reflection: `shadedColor.a = originalAlpha; return clamp()`
             tail = clamp4(c);
             break;
@@ -586,7 +748,8 @@ DEV C4 trace_from_hit(const SceneView& sc, const mcrt_config& cfg, Ray ray, Hit 
 // ---------------------------------------------------------------------------------------------
 // camera.cpp:8-26 and tile_renderer.cpp:42-69
 // ---------------------------------------------------------------------------------------------
-DEV Ray camera_ray(const SceneView& sc, float u, float v, float aspect) {
+template <class SV>
+DEV Ray camera_ray(const SV& sc, float u, float v, float aspect) {
     const FlatHeader* h = sc.hdr;
     float halfH = h->cam_half_h;
     float halfW = halfH * aspect;
@@ -596,7 +759,8 @@ DEV Ray camera_ray(const SceneView& sc, float u, float v, float aspect) {
     return Ray{ld3(h->cam_pos), dir};
 }
 
-DEV Ray lens_ray(const SceneView& sc, float u, float v, float aspect, float aperture, float focusDist,
+template <class SV>
+DEV Ray lens_ray(const SV& sc, float u, float v, float aspect, float aperture, float focusDist,
                  float d0, float d1) {
     Ray pin = camera_ray(sc, u, v, aspect);
     if (aperture < 1e-6f) return pin;
@@ -604,8 +768,8 @@ DEV Ray lens_ray(const SceneView& sc, float u, float v, float aspect, float aper
     V3 focus = pin.o + pin.d * focusDist;
     float angle = kTwoPi * d0;
     float radius = aperture * __builtin_sqrtf(d1);
-    float lx = radius * mcrt_cosf(angle);
-    float ly = radius * mcrt_sinf(angle);
+    float lx = radius * dev_cosf(angle);
+    float ly = radius * dev_sinf(angle);
     V3 origin = ld3(h->cam_pos) + (ld3(h->cam_right) * lx + ld3(h->cam_up) * ly);
     return Ray{origin, normalize(focus - origin)};
 }

@@ -114,7 +114,7 @@ def test_flatten_blob_layout(mcrt):
     blob = mcrt.flatten(sd)
     hdr = np.frombuffer(blob[:16], np.uint32)
     assert hdr[0] == 0x4D435254 and hdr[1] == 12 and hdr[2] == 12 * 272  # 12 meshes, 3264 texels
-    assert len(blob) == 192 + 12 * 160 + 3264 * 16
+    assert len(blob) == 192 + 12 * 160 + 3264 * 16 + 3264 // 16 * 4
     f = np.frombuffer(blob[:192], np.float32)
     assert np.allclose(f[12:15], [0, 18, 50]) and abs(f[15] - np.tan(np.radians(30.0))) < 1e-6  # camera pos, tan(fov/2)
     assert np.allclose(f[16:19], [0, 0, -1]) and np.allclose(f[20:23], [1, 0, 0]) and np.allclose(f[24:27], [0, 1, 0])

@@ -1,0 +1,39 @@
+"""Render one named scenario repeatedly (profiling target for rocprofv3)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import minecraftskin_raytracer_amd as M
+import scenes
+
+CASES = {
+    "base": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=4)),
+    "empty4": (lambda: M.SceneDesc(scenes.simple_scene(cam_pos=(0, 18, 50))), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=4)),
+    "empty1": (lambda: M.SceneDesc(scenes.simple_scene(cam_pos=(0, 18, 50))), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=1)),
+    "b0hard": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=0, samplesPerPixel=4, softShadows=False)),
+    "b0": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=0, samplesPerPixel=4)),
+    "4k": (lambda: scenes.skin_scene("S64", 0), dict(width=3840, height=2160, maxBounces=8, samplesPerPixel=16)),
+}
+name = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+mk, kw = CASES[name]
+cfg = M.Config(**kw)
+ds = M.DeviceScene(mk())
+frame = torch.empty((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda")
+r, k = ds.time_render_device(cfg, frame.data_ptr(), iters)
+print(name, "render_ms", round(r, 4), "trace_kernel_ms", round(k, 4))
+
+import ctypes as C
+from minecraftskin_raytracer_amd import _lib
+lib = _lib.load()
+if hasattr(lib, "mcrt_debug_phase_stamps"):
+    arr = (C.c_uint64 * 16)()
+    lib.mcrt_debug_phase_stamps(arr, 1)           # reset
+    ds.time_render_device(cfg, frame.data_ptr(), 1)
+    if lib.mcrt_debug_phase_stamps(arr, 1) == 0:
+        names = ["prologue+setup", "stream fill", "P primary", "compaction+barrier", "B mt draws", "barrier after B", "C shadow rays",
+                 "barrier after C", "D shade/reflect", "A accumulate"]
+        tot = sum(arr[i] for i in range(10)) or 1
+        for i, nme in enumerate(names):
+            print(f"  {nme:22s} {arr[i]/1e6:10.2f} Mcycles  {100*arr[i]/tot:5.1f}%")
+        print(f"  total wave-cycles {tot/1e6:.1f} M")

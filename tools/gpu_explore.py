@@ -26,6 +26,22 @@ def run(name, sd, **kw):
     rows.append((name, t(sd, **cfg)))
     print(name, rows[-1][1], flush=True)
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "scale":
+        for b in (0, 1, 2, 4):
+            run(f"bounces {b}", s64, maxBounces=b)
+        for sh in (2, 4, 8, 16):
+            run(f"b0 shadowSamples {sh}", s64, maxBounces=0, shadowSamples=sh)
+        run("b0 hard", s64, maxBounces=0, softShadows=False)
+        run("default white b0 hard", default, maxBounces=0, softShadows=False)
+        run("default white b4", default)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "short":
+        run("base S64", s64)
+        run("hard shadows", s64, softShadows=False)
+        run("bounces 0", s64, maxBounces=0)
+        run("empty scene spp4", empty)
+        run("4k b8 spp16", s64, width=3840, height=2160, maxBounces=8, samplesPerPixel=16)
+        sys.exit(0)
     run("base S64", s64)
     run("S64 pose6", scenes.skin_scene("S64", 6))
     run("hard shadows", s64, softShadows=False)
