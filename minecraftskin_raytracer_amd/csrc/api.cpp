@@ -92,11 +92,23 @@ struct mcrt_scene {
     uint32_t alpha_words = 0;
     uint32_t n_meshes = 0;
     DeviceBuffer blob;
-    DeviceBuffer tile_rng, hit_rng, deep_stack;
+    // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
+    DeviceBuffer tile_rng, scol, units, unit_hits[2], tile_mask, queues[10], draws, lit[2], stack, root_sample, counters, hit_rng;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
+
+// per-batch workspace budget (bytes); MCRT_WORKSPACE_MB overrides (tests use a small value to force
+// multi-batch renders)
+size_t workspace_budget() {
+    static const size_t v = [] {
+        const char* e = std::getenv("MCRT_WORKSPACE_MB");
+        long long mb = e ? std::atoll(e) : 0;
+        return static_cast<size_t>(mb > 0 ? mb : 4096) << 20;
+    }();
+    return v;
+}
 
 // fill RenderParams + make sure the workspace exists (allocation only when it has to grow)
 int prepare(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, RenderParams& p) {
@@ -111,13 +123,42 @@ int prepare(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layo
     p.scene_in_lds = fits ? 1 : 0;
     p.lds_alpha_words = fits ? static_cast<int>(s->alpha_words) : 0;
     p.lds_face_entries = fits ? static_cast<int>(s->n_meshes * 6) : 0;
-    fill_launch_geometry(p, target_units());
-    HIP_TRY(s->tile_rng.reserve(tile_rng_bytes(p)));
-    HIP_TRY(s->hit_rng.reserve(hit_rng_bytes(p)));
-    HIP_TRY(s->deep_stack.reserve(deep_stack_bytes(p)));
-    p.tile_rng = tile_rng_bytes(p) ? static_cast<uint32_t*>(s->tile_rng.ptr) : nullptr;
-    p.hit_rng = hit_rng_bytes(p) ? static_cast<uint32_t*>(s->hit_rng.ptr) : nullptr;
-    p.deep_stack = deep_stack_bytes(p) ? static_cast<float*>(s->deep_stack.ptr) : nullptr;
+    const WorkspaceBytes w = plan_workspace(p, target_units(), workspace_budget());
+    HIP_TRY(s->tile_rng.reserve(w.tile_rng));
+    HIP_TRY(s->scol.reserve(w.scol));
+    HIP_TRY(s->units.reserve(w.units));
+    HIP_TRY(s->tile_mask.reserve(w.tile_mask));
+    HIP_TRY(s->unit_hits[0].reserve(w.unit_hits));
+    HIP_TRY(s->unit_hits[1].reserve(w.unit_hits));
+    for (auto& q : s->queues) HIP_TRY(q.reserve(w.queue_each));
+    HIP_TRY(s->draws.reserve(w.draws));
+    HIP_TRY(s->lit[0].reserve(w.lit));
+    HIP_TRY(s->lit[1].reserve(w.lit));
+    HIP_TRY(s->stack.reserve(w.stack));
+    HIP_TRY(s->root_sample.reserve(w.root_sample));
+    HIP_TRY(s->counters.reserve(w.counters));
+    HIP_TRY(s->hit_rng.reserve(w.hit_rng));
+    p.tile_rng = w.tile_rng ? static_cast<uint32_t*>(s->tile_rng.ptr) : nullptr;
+    WaveSpace& ws = p.ws;
+    ws.scol = static_cast<float4*>(s->scol.ptr);
+    ws.units = static_cast<uint4*>(s->units.ptr);
+    ws.tile_mask = static_cast<unsigned long long*>(s->tile_mask.ptr);
+    for (int k = 0; k < 2; ++k) {
+        ws.q_o[k] = static_cast<float4*>(s->queues[0 + k].ptr);
+        ws.q_d[k] = static_cast<float4*>(s->queues[2 + k].ptr);
+        ws.q_p[k] = static_cast<float4*>(s->queues[4 + k].ptr);
+        ws.q_n[k] = static_cast<float4*>(s->queues[6 + k].ptr);
+        ws.q_t[k] = static_cast<float4*>(s->queues[8 + k].ptr);
+    }
+    ws.draws = static_cast<float*>(s->draws.ptr);
+    ws.lit[0] = static_cast<uint32_t*>(s->lit[0].ptr);
+    ws.lit[1] = static_cast<uint32_t*>(s->lit[1].ptr);
+    ws.unit_hits[0] = static_cast<uint32_t*>(s->unit_hits[0].ptr);
+    ws.unit_hits[1] = static_cast<uint32_t*>(s->unit_hits[1].ptr);
+    ws.stack = static_cast<float4*>(s->stack.ptr);
+    ws.root_sample = static_cast<uint32_t*>(s->root_sample.ptr);
+    ws.counters = static_cast<uint32_t*>(s->counters.ptr);
+    ws.hit_rng = w.hit_rng ? static_cast<uint32_t*>(s->hit_rng.ptr) : nullptr;
     return MCRT_OK;
 }
 
@@ -214,10 +255,7 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
 void mcrt_scene_destroy(mcrt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    s->blob.release();
-    s->tile_rng.release();
-    s->hit_rng.release();
-    s->deep_stack.release();
+    s->blob.release();  // the other buffers are released by their destructors below
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     delete s;
@@ -366,12 +404,6 @@ int mcrt_last_timings(mcrt_timings* out) {
     if (!out) return MCRT_ERR_INVALID;
     *out = g_timings;
     return MCRT_OK;
-}
-
-// Diagnostic builds only (-DMCRT_STAMPS): not part of include/mcrt.h, never used by the product.
-int mcrt_debug_phase_stamps(unsigned long long out[16], int reset) {
-    hipError_t e = read_phase_stamps(out, reset != 0);
-    return e == hipSuccess ? MCRT_OK : MCRT_ERR_HIP;
 }
 
 // ---- probes -----------------------------------------------------------------------------------

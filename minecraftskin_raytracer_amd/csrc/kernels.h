@@ -19,6 +19,29 @@ struct Shard {
     int owned_rows;  // number of tile rows owned
 };
 
+// Device workspace of the wavefront pipeline (all HBM; sized for one batch of tile rows in which
+// every sample may hit).
+struct WaveSpace {
+    float4* scol;           // per-sample colours of the units that were handed to the queues
+    uint4* units;           // units of the tiles meshes can touch: {owned tile, first pixel, end pixel, slot base}
+    uint32_t* unit_hits[2]; // per unit: live hit entries of the current / next level (ping-pong by level parity)
+    unsigned long long* tile_mask;  // per owned tile: meshes whose screen bound touches it
+    uint32_t unit_cap;      // capacity of `units`
+    float4* q_o[2];         // hit queues, ping-pong by level parity: ray origin  (.w = root entry, bit-cast)
+    float4* q_d[2];         //                                         ray direction (.w = depth, bit-cast)
+    float4* q_p[2];         //                                         hit point
+    float4* q_n[2];         //                                         hit normal (as intersectMesh returns it)
+    float4* q_t[2];         //                                         texel colour
+    float* draws;           // [cap][2*shadowSamples] soft-shadow draws of the current level
+    uint32_t* lit[2];       // [cap] visible light samples of a level's hits (ping-pong by level parity)
+    float4* stack;          // [cap][stack_stride] level colours of the chain rooted at level-0 entry r
+    uint32_t* root_sample;  // [cap] scol slot of the sample that level-0 entry r belongs to
+    uint32_t* counters;     // [0] number of units in `units` (the only global atomic: one add per touched tile)
+    uint32_t* hit_rng;      // general variant: per-thread 624-word mt19937 states (long streams)
+    uint32_t cap;           // entry capacity (= samples of the largest batch)
+    int stack_stride;       // max(1, maxBounces)
+};
+
 struct RenderParams {
     const uint8_t* scene;  // flat blob in HBM
     mcrt_config cfg;
@@ -26,33 +49,31 @@ struct RenderParams {
     int layout;            // MCRT_LAYOUT_*
     float* out;            // float4 frame or packed rows
     uint32_t* tile_rng;    // owned_tiles x 624 seeded mt19937 words (NULL when no tile draws)
-    uint32_t* hit_rng;     // per-thread 624-word slices for long per-hit streams (NULL normally)
-    float* deep_stack;     // per-thread (max_bounces) x float4 slices when max_bounces > 16
+    WaveSpace ws;
     int draws_per_sample;  // 0, 2 or 4
-    int grid_blocks;
-    int parts_per_tile;    // each tile is split into this many pixel-aligned work units
-    int lds_draw_floats;   // dynamic LDS: per-hit shadow draws of one sub-batch
-    int lds_alpha_words;   // dynamic LDS: alpha-predicate words staged per workgroup (0 = read from HBM)
-    int lds_face_entries;  // dynamic LDS: n_meshes * 6 face-table entries (0 = read FlatMesh from HBM)
-    int scene_in_lds;      // 1 when both tables fit the LDS budget (lean kernel variant allowed)
+    int parts_per_tile;    // a tile that meshes can touch is split into this many pixel-aligned work units
+    int lds_alpha_words;   // dynamic LDS: alpha-predicate words staged per workgroup
+    int lds_face_entries;  // dynamic LDS: n_meshes * 6 face-table entries
+    int scene_in_lds;      // 1 when both tables fit the LDS budget (otherwise the kernels read HBM)
+    int rows_per_batch;    // owned tile rows per pipeline pass
 };
 
 Shard make_shard(const mcrt_config& cfg, int first, int step);
-// diagnostic builds (-DMCRT_STAMPS) only: per-phase wave-cycle sums of the trace kernel
-hipError_t read_phase_stamps(unsigned long long out[16], bool reset);
 
-// workspace requirements (bytes) for a given config + shard
-size_t tile_rng_bytes(const RenderParams& p);
-size_t hit_rng_bytes(const RenderParams& p);
-size_t deep_stack_bytes(const RenderParams& p);
-int render_grid_blocks(const RenderParams& p);
-// chooses parts_per_tile, the dynamic-LDS split and the grid for p.cfg / p.shard
-void fill_launch_geometry(RenderParams& p, int target_units);
+// Sizes of the workspace arrays for p.cfg / p.shard; fills p.parts_per_tile, p.rows_per_batch and
+// p.ws.cap / p.ws.stack_stride.  budget_bytes bounds the per-batch workspace (a batch is never
+// smaller than one tile row).
+struct WorkspaceBytes {
+    size_t tile_rng, scol, units, unit_hits, tile_mask, queue_each, draws, lit, stack, root_sample, counters, hit_rng;
+};
+WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_bytes);
 constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
 constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
+constexpr int kCounterWords = 4096;
 
-// enqueue: tile-RNG seeding (if needed) + the trace kernel.  If ev_k0/ev_k1 are non-null they are
-// recorded on `stream` immediately around the trace kernel launch.
+// enqueue the whole pipeline: tile-RNG seeding (if needed), then per batch of tile rows
+// primary → [mt_draws, shadow, shade] per level → resolve.  If ev_k0/ev_k1 are non-null they are
+// recorded on `stream` around everything after the seeding pre-pass.
 hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t ev_k0, hipEvent_t ev_k1);
 
 hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const float* packed, float* frame,

@@ -1,20 +1,32 @@
 // render_kernels.hip — hand-written HIP kernels for gfx950 (MI355X / CDNA4).
 //
-// The hot path of the reference, TileRenderer::renderTile (tile_renderer.cpp:71-127), as a
-// tile-per-workgroup kernel:
-//   * one workgroup (256 threads = 4 wave64) renders one tile; the work items of a tile are its
-//     (pixel, sample) pairs in the reference's RNG stream order w = pixel*spp + s, processed in
-//     chunks of kChunk items;
-//   * the tile's std::mt19937 jitter/lens stream is regenerated in LDS: the seeded 624-word state
-//     comes from a small pre-pass (one lane per tile, the seeding recurrence is sequential), the
-//     twist is done cooperatively (3 parallel phases over a ping-pong state), tempered draws for
-//     the chunk land in an LDS float buffer;
-//   * per item: camera/lens ray → closest hit over the scene (flat blob, wave-uniform scalar
-//     loads; meshes whose screen bound misses the tile are skipped for primary rays) → miss:
-//     gradient background(u,v); hit: iterative traceRay (soft shadow with a register-only
-//     truncated mt19937, Blinn-Phong, AO, reflection loop folded back to front);
-//   * sample colours go to LDS, then one thread per pixel adds its samples in sample order
-//     (float addition order is part of the result) and stores one coalesced float4.
+// The hot path of the reference, TileRenderer::renderTile (tile_renderer.cpp:71-127) with
+// RayTracer::traceRay underneath, as a wavefront pipeline: every stage is a small, high-occupancy
+// kernel over a dense work list, so the latency-bound pieces (the 397-step mt19937 seeding chain,
+// the dependent slab tests of a shadow ray) are hidden by many resident waves instead of stalling a
+// workgroup, and hit work is spread over the whole chip no matter which tiles hold the character.
+//
+//   seed_tiles      1 lane / tile     mt19937 seeding of the per-tile jitter streams
+//   plan_units      1 wave / tile     which meshes' screen bounds touch the tile; a tile nothing can
+//                                     touch becomes ONE background unit, other tiles are split into
+//                                     pixel-aligned parts (load balance) with colour slots assigned
+//   primary         persistent WGs    pull units by ticket.  Background units: thread per pixel,
+//                                     jitter stream in LDS, gradient, ordered sample sum, coalesced
+//                                     float4 store.  Touched units: thread per sample, camera/lens
+//                                     ray, closest hit over the tile's mesh mask; misses write their
+//                                     sample colour, hits are appended to the level-0 queue
+//   per recursion level L = 0 .. maxBounces:
+//     mt_draws      1 lane / hit      register-only truncated mt19937 → 2·S shadow draws
+//     shadow        1 lane / (hit, light sample)   disk sample → any-hit shadow ray → lit count
+//     shade         1 lane / hit      Blinn-Phong (+AO), reflection ray, closest hit → level L+1
+//                                     queue; chains that end fold their level colours back to front
+//   resolve         1 lane / pixel    ordered sum of the pixel's sample colours (float addition
+//                                     order is part of the result), coalesced float4 store
+// Queue entries live in HBM as SoA float4 arrays (ping-pong between levels).  Every unit owns a
+// fixed slot range (its samples); its hits are compacted to the front of that range with an LDS
+// prefix sum and a per-unit count — NO global atomics on the hot path (a returning atomic on one
+// word sustains only ~88 ops/us on this chip; per-wave queue claims made `primary` atomic-bound).
+// A frame is cut into batches of tile rows so that the worst case (every sample hits) fits.
 // No MFMA: there is no dense contraction anywhere on this path.
 #include "kernels.h"
 #include "rt_core.h"
@@ -26,8 +38,9 @@ using namespace rt;
 constexpr int kBlock = 256;
 constexpr int kChunk = 256;        // work items per chunk: one per thread
 constexpr int kMaxDrawsPerItem = 4;
-constexpr int kDrawCap = 4096;     // LDS floats for the per-hit shadow draws of one sub-batch
-constexpr int kAlphaLdsCap = 4096; // alpha-predicate words staged in LDS (64 Ki texels); larger pools stay in HBM
+constexpr int kJitFloats = 4096;   // LDS floats for one pass of tile-stream draws
+constexpr int kPrimaryGrid = 1024; // persistent primary workgroups (4 per CU)
+constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
 
 // ---------------------------------------------------------------------------------------------
 // tile geometry helpers (TileRenderer::generateTiles, tile_renderer.cpp:18-39)
@@ -119,7 +132,6 @@ __device__ __forceinline__ void stream_fill(TileStream& ts, float* jit, int blk,
     }
     __syncthreads();
 }
-
 // ---------------------------------------------------------------------------------------------
 // primary-ray culling mask of a tile
 // ---------------------------------------------------------------------------------------------
@@ -137,85 +149,154 @@ __device__ __forceinline__ bool mesh_touches_tile(const FlatMesh& m, const TileG
 }
 
 // ---------------------------------------------------------------------------------------------
-// the trace kernel: one workgroup per work unit (a pixel-aligned part of a tile)
-//
-// Per chunk of 256 work items (one per thread), traceRay is run as workgroup phases:
-//   P  primary ray + closest hit (per item)                       → alive lanes = items that hit
-//   loop over recursion levels while any lane is alive:
-//     B  per alive hit (owner lane): register-only mt19937 → 2·S shadow draws into LDS
-//     C  per (hit, shadow sample) pair, one pair per lane: disk sample → any-hit shadow ray,
-//        visible samples counted with LDS atomics          (8 lanes per hit at the default S = 8)
-//     D  per alive hit (owner lane): Blinn-Phong (+AO), reflection ray, closest hit of the next
-//        level; chains that end fold their level colours back to front
-//   A  ordered per-pixel accumulation of the chunk's sample colours, coalesced float4 store
+// scene tables staged in LDS: what candidates index PER LANE (face → texture table, alpha bits)
 // ---------------------------------------------------------------------------------------------
-// In-kernel phase stamps: diagnostic builds only (-DMCRT_STAMPS).  Per wave, lane 0 adds the
-// s_memtime delta of each phase to a global table that no other code reads.
-#ifdef MCRT_STAMPS
-__device__ unsigned long long g_phase_cycles[16];
-#define STAMP_BEGIN()                        \
-    unsigned long long stamp_t0_ = clock64(); \
-    unsigned long long stamp_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define STAMP(slot)                          \
-    do {                                     \
-        unsigned long long t1_ = clock64();  \
-        stamp_acc_[slot] += t1_ - stamp_t0_; \
-        stamp_t0_ = t1_;                     \
-    } while (0)
-#define STAMP_FLUSH()                                                                    \
-    do {                                                                                 \
-        if ((threadIdx.x & 63) == 0)                                                     \
-            for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phase_cycles[i_], stamp_acc_[i_]); \
-    } while (0)
-#else
-#define STAMP_BEGIN() do { } while (0)
-#define STAMP(slot) do { } while (0)
-#define STAMP_FLUSH() do { } while (0)
-#endif
-
-#ifndef MCRT_WAVES_PER_EU
-#define MCRT_WAVES_PER_EU 2
-#endif
-// kGeneral = false is the lean common variant: no AO, per-hit RNG streams of at most 227 draws,
-// at most 16 bounces.  It performs no store through a generic or global pointer other than the
-// frame, so every uniform read of the scene blob stays a scalar load (s_load) — with the rare
-// features compiled in, their possible aliasing turns the mesh loop's loads into vector loads.
-template <bool kGeneral>
-__global__ __launch_bounds__(kBlock, MCRT_WAVES_PER_EU) void render_units_kernel(
-    const uint8_t* __restrict__ scene_blob, const uint32_t* __restrict__ tile_rng, float4* __restrict__ out_frame,
-    const RenderParams p, const int n_units) {
-    __shared__ uint32_t s_mt[2 * 624];
-    __shared__ float s_jit[kChunk * kMaxDrawsPerItem];
-    __shared__ float4 s_col[kChunk];
-    __shared__ float4 s_hp[kChunk];  // alive hit k: point
-    __shared__ float4 s_hn[kChunk];  // alive hit k: normal used by its shadow rays
-    __shared__ unsigned int s_lit[kChunk];
-    __shared__ float4 s_carry[2];
-    __shared__ unsigned long long s_mask;
-    __shared__ int s_wave_cnt[kBlock / 64];
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    // dynamic LDS: [per-hit shadow draws][face table: 4 ints per (mesh, face)][alpha-predicate words]
-    float* s_draws = reinterpret_cast<float*>(s_dyn);
-    int* s_faces = reinterpret_cast<int*>(s_dyn + static_cast<size_t>(p.lds_draw_floats) * 4);
-    uint32_t* s_abits = reinterpret_cast<uint32_t*>(s_dyn + static_cast<size_t>(p.lds_draw_floats) * 4 +
-                                                    static_cast<size_t>(p.lds_face_entries) * 16);
-
-    const SceneView scg = view_of(scene_blob);
-    const mcrt_config& cfg = p.cfg;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    // Stage what the per-candidate tests read with per-lane indices — the face → texture table and
-    // the alpha predicates — in LDS (the host launches this kernel only when both fit).
-    for (int i = tid; i < p.lds_alpha_words; i += kBlock) s_abits[i] = scg.abits[i];
-    for (int i = tid; i < p.lds_face_entries; i += kBlock) {
-        const FlatMesh& fm = scg.meshes[i / 6];
+struct LdsTables {
+    const MCRT_LDS uint32_t* abits;
+    const MCRT_LDS int* faces;
+};
+// dyn = dynamic LDS base; layout [face table: 4 ints per (mesh, face)][alpha words].  Collective.
+__device__ __forceinline__ LdsTables stage_tables(const SceneView& g, const RenderParams& p, unsigned char* dyn) {
+    int* s_faces = reinterpret_cast<int*>(dyn);
+    uint32_t* s_abits = reinterpret_cast<uint32_t*>(dyn + static_cast<size_t>(p.lds_face_entries) * 16);
+    for (int i = threadIdx.x; i < p.lds_alpha_words; i += blockDim.x) s_abits[i] = g.abits[i];
+    for (int i = threadIdx.x; i < p.lds_face_entries; i += blockDim.x) {
+        const FlatMesh& fm = g.meshes[i / 6];
         const int f = i - (i / 6) * 6;
         s_faces[4 * i + 0] = fm.tex_off[f];
         s_faces[4 * i + 1] = fm.tex_w[f];
         s_faces[4 * i + 2] = fm.tex_h[f];
         s_faces[4 * i + 3] = 0;
     }
-    const SceneViewLds sc = view_with_lds(scg, (const MCRT_LDS uint32_t*)s_abits, (const MCRT_LDS int*)s_faces);
+    __syncthreads();
+    return LdsTables{(const MCRT_LDS uint32_t*)s_abits, (const MCRT_LDS int*)s_faces};
+}
+template <bool kLds>
+struct ViewSel;
+template <>
+struct ViewSel<true> {
+    using type = SceneViewLds;
+    static __device__ __forceinline__ type make(const SceneView& g, const RenderParams& p, unsigned char* dyn) {
+        LdsTables t = stage_tables(g, p, dyn);
+        return view_with_lds(g, t.abits, t.faces);
+    }
+};
+template <>
+struct ViewSel<false> {
+    using type = SceneView;
+    static __device__ __forceinline__ type make(const SceneView& g, const RenderParams&, unsigned char*) { return g; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// queue helpers
+// ---------------------------------------------------------------------------------------------
+// counters[0]: number of planned units (one atomic add per touched tile, in plan_units)
+constexpr int kCntUnits = 0;
+
+// Rank of this thread's item among the workgroup's flagged items, and their total: ballot per wave,
+// four wave counts through LDS.  Collective (two barriers: the counts are reusable right after).
+__device__ __forceinline__ int block_rank(bool flag, int* s_wcnt, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0;
+    total = 0;
+#pragma unroll
+    for (int wv = 0; wv < kBlock / 64; ++wv) {
+        const int c = s_wcnt[wv];
+        if (wv < wave) before += c;
+        total += c;
+    }
+    __syncthreads();
+    return before + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void push_entry(const WaveSpace& ws, int parity, uint32_t e, const Ray& ray, const Hit& hit,
+                                           uint32_t root, int depth) {
+    ws.q_o[parity][e] = make_float4(ray.o.x, ray.o.y, ray.o.z, __uint_as_float(root));
+    ws.q_d[parity][e] = make_float4(ray.d.x, ray.d.y, ray.d.z, __int_as_float(depth));
+    ws.q_p[parity][e] = make_float4(hit.p.x, hit.p.y, hit.p.z, 0.0f);
+    ws.q_n[parity][e] = make_float4(hit.n.x, hit.n.y, hit.n.z, 0.0f);
+    ws.q_t[parity][e] = make_float4(hit.tex.r, hit.tex.g, hit.tex.b, hit.tex.a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan_units: one wave per tile of the batch
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void plan_units_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
+                                                        const int tile_base, const int n_tiles) {
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const SceneView sc = view_of(scene_blob);
+    const mcrt_config& cfg = p.cfg;
+    const WaveSpace& ws = p.ws;
+    const int tile = tile_base + t;
+    const TileGeom tg = tile_of(p, tile);
+    const int lane = threadIdx.x;
+    const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
+    const bool cull = sc.hdr->cull_ok != 0 && !dof && sc.n_meshes < 64;
+    const float aspect = static_cast<float>(cfg.width) / static_cast<float>(cfg.height);
+    bool touch = lane < sc.n_meshes;
+    if (touch && cull) touch = mesh_touches_tile(sc.meshes[lane], tg, cfg, aspect);
+    unsigned long long mask = __ballot(touch);
+    if (!cull && sc.n_meshes > 0) mask = ~0ull;
+    if (lane != 0) return;
+    ws.tile_mask[tile] = mask;
+    if (mask == 0ull) return;  // background tile: rendered whole by `primary`, never queued
+    const uint32_t spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
+    const uint32_t npix = static_cast<uint32_t>(tg.w) * static_cast<uint32_t>(tg.h);
+    const uint32_t parts = static_cast<uint32_t>(p.parts_per_tile);
+    const uint32_t per = (npix + parts - 1u) / parts;
+    const uint32_t used = (npix + per - 1u) / per;
+    const uint32_t slot0 = atomicAdd(&ws.counters[kCntUnits], used);
+    // slot ranges are a fixed function of the tile: no atomics, capacity = the batch's samples
+    const uint32_t base = static_cast<uint32_t>(t) * static_cast<uint32_t>(cfg.tile_size) * static_cast<uint32_t>(cfg.tile_size) * spp;
+    for (uint32_t i = 0; i < used; ++i) {
+        const uint32_t a = i * per, b = min(npix, a + per);
+        ws.units[slot0 + i] = make_uint4(static_cast<uint32_t>(tile), a, b, base + a * spp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// primary: persistent workgroups; touched units first, then the background tiles
+// ---------------------------------------------------------------------------------------------
+// the tile's seeded mt19937 state into LDS and the stream position of the first draw
+__device__ __forceinline__ void stream_open(TileStream& ts, uint32_t* s_mt, const uint32_t* __restrict__ tile_rng, int tile,
+                                            unsigned long long first_draw, int& sblk, int& soff) {
+    ts.st = s_mt;
+    ts.cur = 0;
+    ts.block = -1;
+    const uint32_t* src = tile_rng + static_cast<size_t>(tile) * 624;
+    for (int e = threadIdx.x; e < 624; e += kBlock) s_mt[e] = src[e];
+    if (first_draw < 0xffffffffull) {
+        const uint32_t fd = static_cast<uint32_t>(first_draw);
+        sblk = static_cast<int>(fd / 624u);
+        soff = static_cast<int>(fd - static_cast<uint32_t>(sblk) * 624u);
+    } else {
+        sblk = static_cast<int>(first_draw / 624ull);
+        soff = static_cast<int>(first_draw - static_cast<unsigned long long>(sblk) * 624ull);
+    }
+    __syncthreads();
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restrict__ scene_blob,
+                                                         const uint32_t* __restrict__ tile_rng,
+                                                         float4* __restrict__ out_frame, const RenderParams p,
+                                                         const int tile_base, const int n_tiles) {
+    __shared__ uint32_t s_mt[2 * 624];
+    __shared__ float s_jit[kJitFloats];
+    __shared__ float4 s_col[kChunk];
+    __shared__ float4 s_carry[2];
+    __shared__ int s_wcnt[kBlock / 64];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+
+    const SceneView scg = view_of(scene_blob);
+    const typename ViewSel<kLds>::type sc = ViewSel<kLds>::make(scg, p, s_dyn);
+    const mcrt_config& cfg = p.cfg;
+    const WaveSpace& ws = p.ws;
+    const int tid = threadIdx.x;
     const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const int dd = p.draws_per_sample;
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
@@ -224,69 +305,27 @@ __global__ __launch_bounds__(kBlock, MCRT_WAVES_PER_EU) void render_units_kernel
     float focusDist = cfg.focus_distance;
     if (focusDist <= 0.0f) focusDist = sc.hdr->cam_focus_auto;
     const float inv_spp = 1.0f / static_cast<float>(spp);
-    const float* fb = sc.hdr->background;
-    const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
-    const V3 lpos = ld3(sc.hdr->light_pos);
+    const uint32_t n_units = ws.counters[kCntUnits];
+    TileStream ts;
+    ts.st = s_mt;
+    ts.cur = 0;
+    ts.block = -1;
+    int sblk = 0, soff = 0;
 
-    const int mode = shadow_mode(sc, cfg);
-    const int S = cfg.shadow_samples;
-    const int pairs_per_hit = (mode == SHADOW_SOFT) ? S : 1;
-    // the disk samples of a hit are spread over lanes when their draws fit the LDS budget
-    const bool spread = (mode != SHADOW_SOFT) || (2 * S <= p.lds_draw_floats);
-    const int batch_hits = (mode == SHADOW_SOFT && spread) ? max(1, min(kChunk, p.lds_draw_floats / (2 * S))) : kChunk;
-
-    uint32_t* my_hit_rng = nullptr;
-    C4 local_stack[kMaxStack];
-    C4* stack = local_stack;
-    if constexpr (kGeneral) {
-        if (p.hit_rng) my_hit_rng = p.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + tid) * 624;
-        if (p.deep_stack)
-            stack = reinterpret_cast<C4*>(p.deep_stack) +
-                    (static_cast<size_t>(blockIdx.x) * kBlock + tid) * static_cast<size_t>(max(cfg.max_bounces, 1));
-    }
-
-    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-        const int tile = unit / p.parts_per_tile;
-        const int part = unit - tile * p.parts_per_tile;
+    // ================= units of tiles that meshes can touch: thread per sample =================
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint4 ud = ws.units[u];
+        const int tile = static_cast<int>(ud.x);
+        const unsigned pp0 = ud.y, pp1 = ud.z;
+        const uint32_t slot_base = ud.w;
         const TileGeom tg = tile_of(p, tile);
-        // all index arithmetic is 32-bit: a work item is (pixel, sample), never a flat 64-bit index
-        const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
-        const unsigned pix_per_part = (npix + p.parts_per_tile - 1) / p.parts_per_tile;
-        const unsigned pp0 = static_cast<unsigned>(part) * pix_per_part;
-        const unsigned pp1 = min(npix, pp0 + pix_per_part);
-        if (pp0 >= pp1) continue;  // uniform: clipped tiles have fewer parts
-        // position of the unit's first draw in the tile's mt19937 stream (one 64-bit division per unit)
-        const unsigned long long first_draw = static_cast<unsigned long long>(pp0) * spp * dd;
-        int sblk = static_cast<int>(first_draw / 624ull);
-        int soff = static_cast<int>(first_draw - static_cast<unsigned long long>(sblk) * 624ull);
-
-        // ---- per-unit setup: RNG state into LDS, culling mask ----
+        const unsigned long long mesh_mask = ws.tile_mask[tile];
         __syncthreads();
-        TileStream ts;
-        ts.st = s_mt;
-        ts.cur = 0;
-        ts.block = -1;
-        if (dd > 0) {
-            const uint32_t* src = tile_rng + static_cast<size_t>(tile) * 624;
-            for (int e = tid; e < 624; e += kBlock) s_mt[e] = src[e];
-        }
-        if (tid < 64) {
-            bool touch = true;
-            const bool cull = sc.hdr->cull_ok != 0 && !dof;
-            if (tid < sc.n_meshes && cull) touch = mesh_touches_tile(sc.meshes[tid], tg, cfg, aspect);
-            unsigned long long m = __ballot(touch && tid < sc.n_meshes);
-            if (tid == 0) s_mask = (sc.n_meshes < 64 && cull) ? m : ~0ull;
-        }
-        __syncthreads();
-        const unsigned long long mesh_mask = s_mask;
-        STAMP(0);  // prologue + unit setup
+        if (dd > 0) stream_open(ts, s_mt, tile_rng, tile, static_cast<unsigned long long>(pp0) * spp * dd, sblk, soff);
 
-        // chunk cursor: the chunk starts at sample cs of pixel cp
-        unsigned cp = pp0, cs = 0;
-        int parity = 0;
+        uint32_t unit_hits = 0;      // hits so far: they occupy slots slot_base .. slot_base + unit_hits
+        unsigned cp = pp0, cs = 0;   // chunk cursor: sample cs of pixel cp
         while (cp < pp1) {
-            // items left in the unit, clamped to one chunk (the product cannot overflow: it is only
-            // formed when fewer than kChunk pixels remain and then compared after a division)
             const unsigned pix_left = pp1 - cp;
             int n = kChunk;
             if (pix_left <= static_cast<unsigned>(kChunk)) {
@@ -299,19 +338,15 @@ __global__ __launch_bounds__(kBlock, MCRT_WAVES_PER_EU) void render_units_kernel
                 sblk += soff / 624;
                 soff %= 624;
             }
-            STAMP(1);  // tile stream fill (incl. catch-up twists)
-
-            // ---- P: primary ray of this thread's item ----
-            bool alive = false, query = false;
+            bool is_hit = false;
             Ray ray{mk(0, 0, 0), mk(0, 0, 0)};
             Hit hit;
             hit.hit = false;
-            C4 col{0.0f, 0.0f, 0.0f, 0.0f};
-            float su = 0.5f, sv = 0.5f;
-            int depth = 0, top = 0;
+            uint32_t sample_slot = 0;
             if (tid < n) {
                 const unsigned sidx = cs + tid;  // < spp + kChunk
-                const unsigned pix = cp + sidx / static_cast<unsigned>(spp);
+                const unsigned dpix = sidx / static_cast<unsigned>(spp);
+                const unsigned pix = cp + dpix;
                 const unsigned uly = pix / static_cast<unsigned>(tg.w);
                 const int ly = static_cast<int>(uly);
                 const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
@@ -324,133 +359,116 @@ __global__ __launch_bounds__(kBlock, MCRT_WAVES_PER_EU) void render_units_kernel
                     jy = jd[1];
                     dpos = 2;
                 }
-                su = (static_cast<float>(px) + jx) / fW;
-                sv = (static_cast<float>(py) + jy) / fH;
+                const float su = (static_cast<float>(px) + jx) / fW;
+                const float sv = (static_cast<float>(py) + jy) / fH;
+                sample_slot = slot_base + (pix - pp0) * static_cast<uint32_t>(spp) + (sidx - dpix * static_cast<unsigned>(spp));
                 ray = dof ? lens_ray(sc, su, sv, aspect, cfg.aperture, focusDist, jd[dpos], jd[dpos + 1])
                           : camera_ray(sc, su, sv, aspect);
-                query = true;
+                hit = hit_scene(sc, ray, mesh_mask);
+                C4 col;
+                if (!hit.hit)
+                    col = background(sc, cfg, su, sv);  // tile_renderer.cpp:111-114
+                else if (cfg.max_bounces < 0)
+                    col = background(sc, cfg, 0.5f, 0.5f);  // raytracer.cpp:86-90 (depth 0 > maxBounces)
+                else
+                    is_hit = true;
+                if (!is_hit) ws.scol[sample_slot] = make_float4(col.r, col.g, col.b, col.a);  // final for misses
             }
-            STAMP(2);  // P: primary
-            // ---- recursion levels; round 0 resolves the primary rays, round r the depth-r reflections ----
-            for (int round = 0;; ++round) {
-                // Q: the ONE closest-hit site of the kernel
-                if (query) {
-                    hit = hit_scene(sc, ray, round == 0 ? mesh_mask : ~0ull);
-                    query = false;
-                    if (round == 0) {
-                        if (!hit.hit) {
-                            col = background(sc, cfg, su, sv);  // tile_renderer.cpp:111-114
-                        } else if (cfg.max_bounces < 0) {
-                            col = background(sc, cfg, 0.5f, 0.5f);  // raytracer.cpp:86-90 (depth 0 > maxBounces)
-                        } else {
-                            alive = true;
-                        }
-                    } else if (hit.hit) {
-                        alive = true;
-                    } else {  // bounced ray missed → flat background (raytracer.cpp:94-102), chain ends
-                        C4 tail = flat_bg;
-                        while (top > 0) tail = fold_reflection(stack[--top], tail);
-                        col = tail;
-                    }
-                }
-                // compact the alive lanes: k = rank of this lane's hit among the chunk's alive hits
-                const unsigned long long bal = __ballot(alive);
-                if (lane == 0) s_wave_cnt[wave] = __popcll(bal);
-                __syncthreads();
-                int base = 0, n_alive = 0;
-#pragma unroll
-                for (int wv = 0; wv < kBlock / 64; ++wv) {
-                    const int c = s_wave_cnt[wv];
-                    if (wv < wave) base += c;
-                    n_alive += c;
-                }
-                STAMP(3);  // Q + compaction + its barrier
-                if (n_alive == 0) break;  // uniform
-                const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
-
-                float vis = 1.0f;
-                if (spread) {
-                    if (alive) {
-                        const V3 sn = (mode == SHADOW_HARD) ? normalize(hit.n) : hit.n;
-                        s_hp[k] = make_float4(hit.p.x, hit.p.y, hit.p.z, 0.0f);
-                        s_hn[k] = make_float4(sn.x, sn.y, sn.z, 0.0f);
-                        s_lit[k] = 0u;
-                    }
-                    for (int b0 = 0; b0 < n_alive; b0 += batch_hits) {
-                        const int nb = min(batch_hits, n_alive - b0);
-                        // ---- B: shadow draws of the hits in this sub-batch ----
-                        if (mode == SHADOW_SOFT && alive && k >= b0 && k < b0 + nb) {
-                            float* dst = s_draws + (k - b0) * 2 * S;
-                            if constexpr (kGeneral) {
-                                HitRng rng;
-                                rng.seed(shadow_seed(hit.p, depth), 2 * S, my_hit_rng);
-                                for (int i = 0; i < 2 * S; ++i) dst[i] = rng.uniform();
-                            } else {
-#ifdef MCRT_ABL_NO_B  // timing ablation only: constant draws instead of the mt19937 chain
-                                for (int i = 0; i < 2 * S; ++i) dst[i] = 0.25f + 0.03f * i;
-#else
-                                MtShort rng;
-                                rng.seed(shadow_seed(hit.p, depth));
-                                for (int i = 0; i < 2 * S; ++i) dst[i] = rng.uniform();
-#endif
-                            }
-                        }
-                        STAMP(4);  // B: mt19937 draws
-                        __syncthreads();
-                        STAMP(5);  // barrier after B
-                        // ---- C: one (hit, light sample) pair per lane; the ONE any-hit site ----
-#ifdef MCRT_ABL_NO_C  // timing ablation only: no shadow rays
-                        for (int q = tid; q < nb * pairs_per_hit; q += kBlock) atomicAdd(&s_lit[b0 + q / pairs_per_hit], 1u);
-                        if (false)
-#endif
-                        for (int q = tid; q < nb * pairs_per_hit; q += kBlock) {
-                            const int kk = q / pairs_per_hit;
-                            const int j = q - kk * pairs_per_hit;
-                            const float4 hp = s_hp[b0 + kk], hn = s_hn[b0 + kk];
-                            const V3 P = mk(hp.x, hp.y, hp.z), N = mk(hn.x, hn.y, hn.z);
-                            V3 target = lpos;
-                            if (mode == SHADOW_SOFT) {
-                                const float* dr = s_draws + kk * 2 * S + 2 * j;
-                                target = light_sample_position(sc, P, dr[0], dr[1]);
-                            }
-                            if (!in_shadow_inline(sc, P, N, target)) atomicAdd(&s_lit[b0 + kk], 1u);
-                        }
-                        STAMP(6);  // C: shadow rays
-                        __syncthreads();
-                        STAMP(7);  // barrier after C
-                    }
-                    if (alive) {
-                        const unsigned int lit = s_lit[k];
-                        vis = (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S)
-                                                    : (lit ? 1.0f : 0.0f);
-                    }
-                } else if (alive) {
-                    if constexpr (kGeneral) vis = hit_visibility(sc, cfg, hit, depth, my_hit_rng);  // very large S: sequential
-                }
-
-                // ---- D: colour of the level; the reflection ray goes to the next round's Q ----
-                if (alive) {
-                    C4 c = kGeneral ? level_color(sc, cfg, ray.o, hit, depth, vis, my_hit_rng)
-                                    : shade(sc, hit, normalize(ray.o - hit.p), vis);
-                    alive = false;
-                    if (depth >= cfg.max_bounces) {
-                        C4 tail = clamp4(c);
-                        while (top > 0) tail = fold_reflection(stack[--top], tail);
-                        col = tail;
-                    } else {
-                        stack[top++] = c;
-                        ray = reflect_ray(ray, hit);
-                        ++depth;
-                        query = true;
-                    }
-                }
-                STAMP(8);  // D: shade + reflection ray
+            // hits → dense entries at the front of the unit's slot range (no global atomics)
+            int total = 0;
+            const int rank = block_rank(is_hit, s_wcnt, total);
+            if (is_hit) {
+                const uint32_t e = slot_base + unit_hits + static_cast<uint32_t>(rank);
+                push_entry(ws, 0, e, ray, hit, e, 0);
+                ws.root_sample[e] = sample_slot;
             }
+            unit_hits += static_cast<uint32_t>(total);
+            const unsigned adv = cs + static_cast<unsigned>(n);
+            cp += adv / static_cast<unsigned>(spp);
+            cs = adv % static_cast<unsigned>(spp);
+        }
+        if (tid == 0) ws.unit_hits[0][u] = unit_hits;
+    }
 
-            if (tid < n) s_col[tid] = make_float4(col.r, col.g, col.b, col.a);
+    // ================= background tiles: nothing can be hit, no ray is needed =================
+    // a whole 256-pixel pass of draws fits the LDS buffer → thread per pixel, no colour staging
+    const bool pixel_path = static_cast<long long>(kBlock) * spp * dd <= kJitFloats;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tile = tile_base + t;
+        if (ws.tile_mask[tile] != 0ull) continue;  // uniform
+        const TileGeom tg = tile_of(p, tile);
+        const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
+        __syncthreads();
+        if (dd > 0) stream_open(ts, s_mt, tile_rng, tile, 0ull, sblk, soff);
+
+        if (pixel_path) {
+            for (unsigned q0 = 0; q0 < npix; q0 += kBlock) {
+                const int npx = static_cast<int>(min(static_cast<unsigned>(kBlock), npix - q0));
+                if (dd > 0) {
+                    stream_fill(ts, s_jit, sblk, soff, npx * spp * dd);
+                    soff += npx * spp * dd;
+                    sblk += soff / 624;
+                    soff %= 624;
+                }
+                if (tid < npx) {
+                    const unsigned pix = q0 + tid;
+                    const unsigned uly = pix / static_cast<unsigned>(tg.w);
+                    const int ly = static_cast<int>(uly);
+                    const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
+                    const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
+                    float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
+                    for (int s = 0; s < spp; ++s) {
+                        float jx = 0.5f, jy = 0.5f;
+                        if (spp > 1) {
+                            jx = s_jit[(tid * spp + s) * dd];
+                            jy = s_jit[(tid * spp + s) * dd + 1];
+                        }
+                        const C4 c = background(sc, cfg, (fx + jx) / fW, (fy + jy) / fH);  // tile_renderer.cpp:111-114
+                        ar += c.r;
+                        ag += c.g;
+                        ab += c.b;
+                        aa += c.a;
+                    }
+                    const int row = (p.layout == MCRT_LAYOUT_PACKED) ? (tg.owned_row * cfg.tile_size + ly) : (tg.y + ly);
+                    out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
+                        make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp);
+                }
+                if (dd > 0) __syncthreads();  // s_jit is refilled by the next pass
+            }
+            continue;
+        }
+
+        // long per-pixel streams: thread per sample, ordered accumulation through LDS
+        unsigned cp = 0, cs = 0;
+        int parity = 0;
+        while (cp < npix) {
+            const unsigned pix_left = npix - cp;
+            int n = kChunk;
+            if (pix_left <= static_cast<unsigned>(kChunk)) {
+                const unsigned long long left = static_cast<unsigned long long>(pix_left) * spp - cs;
+                if (left < static_cast<unsigned long long>(kChunk)) n = static_cast<int>(left);
+            }
+            if (dd > 0) {
+                stream_fill(ts, s_jit, sblk, soff, n * dd);
+                soff += n * dd;
+                sblk += soff / 624;
+                soff %= 624;
+            }
+            if (tid < n) {
+                const unsigned sidx = cs + tid;
+                const unsigned pix = cp + sidx / static_cast<unsigned>(spp);
+                const unsigned uly = pix / static_cast<unsigned>(tg.w);
+                const int ly = static_cast<int>(uly);
+                const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
+                float jx = 0.5f, jy = 0.5f;
+                if (spp > 1) {
+                    jx = s_jit[tid * dd];
+                    jy = s_jit[tid * dd + 1];
+                }
+                const C4 c = background(sc, cfg, (static_cast<float>(tg.x + lx) + jx) / fW, (static_cast<float>(tg.y + ly) + jy) / fH);
+                s_col[tid] = make_float4(c.r, c.g, c.b, c.a);
+            }
             __syncthreads();
-
-            // ---- A: ordered per-pixel accumulation (tile_renderer.cpp:116-124) ----
             // pixel cp+i owns chunk items [i*spp - cs, (i+1)*spp - cs) clipped to [0, n)
             const int n_pix = static_cast<int>((cs + n - 1) / static_cast<unsigned>(spp)) + 1;
             for (int i = tid; i < n_pix; i += kBlock) {
@@ -471,22 +489,263 @@ __global__ __launch_bounds__(kBlock, MCRT_WAVES_PER_EU) void render_units_kernel
                     const int ly = static_cast<int>(uly);
                     const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
                     const int row = (p.layout == MCRT_LAYOUT_PACKED) ? (tg.owned_row * cfg.tile_size + ly) : (tg.y + ly);
-                    float4* dst = out_frame + static_cast<size_t>(row) * cfg.width + (tg.x + lx);
-                    *dst = make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
+                    out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
+                        make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
                 } else {
                     s_carry[parity] = acc;
                 }
             }
             __syncthreads();
-            STAMP(9);  // A: accumulate + store
-            // advance the cursor
             const unsigned adv = cs + static_cast<unsigned>(n);
             cp += adv / static_cast<unsigned>(spp);
             cs = adv % static_cast<unsigned>(spp);
             parity ^= 1;
         }
     }
-    STAMP_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// level kernels.  Level 0 entries sit at the front of each unit's slot range (count per unit, no
+// atomics).  From level 1 on the queue is dense: `shade` appends with ONE workgroup-aggregated
+// atomic per 256-entry block — a few thousand per frame instead of one per wave — because the
+// deeper levels are sparse and a ray has microseconds of dependent latency: they need dense
+// launches to keep enough rays in flight.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCntDense = 8;  // counters[kCntDense + L] = entries of level L >= 1
+
+// Calls body(first_entry, n_valid) for consecutive blocks of up to kBlock entries of `level`;
+// every thread of the workgroup makes the same calls (collectives inside the body are allowed).
+template <class F>
+__device__ __forceinline__ void for_each_entry_block(const WaveSpace& ws, int level, F&& body) {
+    if (level == 0) {
+        const uint32_t n_units = ws.counters[kCntUnits];
+        for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+            const uint32_t base = ws.units[u].w;
+            const uint32_t count = ws.unit_hits[0][u];
+            for (uint32_t k0 = 0; k0 < count; k0 += kBlock) body(base + k0, min(static_cast<uint32_t>(kBlock), count - k0));
+        }
+    } else {
+        const uint32_t count = ws.counters[kCntDense + level];
+        for (uint32_t k0 = blockIdx.x * kBlock; k0 < count; k0 += gridDim.x * kBlock)
+            body(k0, min(static_cast<uint32_t>(kBlock), count - k0));
+    }
+}
+
+// mt_draws: the sequential 397-step seeding recurrence, one hit per lane; with thousands of
+// resident waves the dependent integer chain is hidden by occupancy
+template <bool kGeneral>
+__global__ __launch_bounds__(kBlock) void mt_draws_kernel(const RenderParams p, const int level) {
+    const WaveSpace& ws = p.ws;
+    const int par = level & 1;
+    const int S = p.cfg.shadow_samples;
+    uint32_t* my_rng = nullptr;
+    if constexpr (kGeneral)
+        my_rng = ws.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * 624;
+    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) {
+        if (threadIdx.x >= n) return;
+        const uint32_t e = first + threadIdx.x;
+        const float4 hp = ws.q_p[par][e];
+        const int depth = __float_as_int(ws.q_d[par][e].w);
+        const uint32_t seed = shadow_seed(mk(hp.x, hp.y, hp.z), depth);
+        float* dst = ws.draws + static_cast<size_t>(e) * 2 * S;
+        if constexpr (kGeneral) {
+            HitRng rng;
+            rng.seed(seed, 2 * S, my_rng);
+            for (int i = 0; i < 2 * S; ++i) dst[i] = rng.uniform();
+        } else {
+            MtShort rng;
+            rng.seed(seed);
+            for (int i = 0; i < 2 * S; ++i) dst[i] = rng.uniform();
+        }
+    });
+}
+
+// shadow: one (hit, light sample) pair per lane
+template <bool kLds>
+__global__ __launch_bounds__(kBlock) void shadow_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
+                                                        const int level) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const SceneView scg = view_of(scene_blob);
+    const typename ViewSel<kLds>::type sc = ViewSel<kLds>::make(scg, p, s_dyn);
+    const WaveSpace& ws = p.ws;
+    const int par = level & 1;
+    const int mode = shadow_mode(sc, p.cfg);
+    const int S = p.cfg.shadow_samples;
+    const uint32_t pairs_per_hit = (mode == SHADOW_SOFT) ? static_cast<uint32_t>(S) : 1u;
+    // groups of pairs_per_hit consecutive lanes belong to one hit; when that is a power of two
+    // <= 64 the lit count is a ballot + popcount, otherwise atomics on a zeroed counter
+    const bool pow2 = (pairs_per_hit & (pairs_per_hit - 1u)) == 0u && pairs_per_hit <= 64u;
+    const V3 lpos = ld3(sc.hdr->light_pos);
+    const uint32_t lane = threadIdx.x & 63u;
+    // one wave-aligned group of up to 64 consecutive (entry, sample) pairs of the range `first` .. +total
+    auto trace_pairs = [&](uint32_t first, uint32_t q0, uint32_t total) {
+        const uint32_t q = q0 + lane;
+        bool visible = false;
+        uint32_t e = 0;
+        if (q < total) {
+            const uint32_t k = q / pairs_per_hit;
+            const uint32_t j = q - k * pairs_per_hit;
+            e = first + k;
+            const float4 hp = ws.q_p[par][e], hn = ws.q_n[par][e];
+            const V3 P = mk(hp.x, hp.y, hp.z);
+            V3 N = mk(hn.x, hn.y, hn.z);
+            if (mode == SHADOW_HARD) N = normalize(N);
+            V3 target = lpos;
+            if (mode == SHADOW_SOFT) {
+                const float* dr = ws.draws + static_cast<size_t>(e) * 2 * S + 2 * j;
+                target = light_sample_position(sc, P, dr[0], dr[1]);
+            }
+            visible = !in_shadow_inline(sc, P, N, target);
+        }
+        if (pow2) {
+            const unsigned long long m = __ballot(visible);
+            if (q < total && (lane & (pairs_per_hit - 1u)) == 0u) {
+                const unsigned long long grp =
+                    (pairs_per_hit == 64u) ? m : ((m >> lane) & ((1ull << pairs_per_hit) - 1ull));
+                ws.lit[par][e] = static_cast<uint32_t>(__popcll(grp));
+            }
+        } else if (visible) {
+            atomicAdd(&ws.lit[par][e], 1u);
+        }
+    };
+    if (level > 0 && pow2) {
+        // dense queue: stride over PAIRS so that even a sparse level spreads over all workgroups
+        const uint32_t count = ws.counters[kCntDense + level];
+        const unsigned long long total = static_cast<unsigned long long>(count) * pairs_per_hit;
+        const unsigned long long step = static_cast<unsigned long long>(gridDim.x) * kBlock;
+        for (unsigned long long q0 = static_cast<unsigned long long>(blockIdx.x) * kBlock + (threadIdx.x & ~63u); q0 < total; q0 += step) {
+            // 64 consecutive pairs start at entry q0 / pairs_per_hit exactly (pairs_per_hit divides 64)
+            const uint32_t first = static_cast<uint32_t>(q0 / pairs_per_hit);
+            const uint32_t left = static_cast<uint32_t>(min(total - q0, 64ull));
+            trace_pairs(first, 0u, left);
+        }
+        return;
+    }
+    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) {
+        if (!pow2) {
+            if (threadIdx.x < n) ws.lit[par][first + threadIdx.x] = 0u;
+            __syncthreads();
+        }
+        const uint32_t total = n * pairs_per_hit;
+        // every lane of a wave runs the same number of iterations (ballot inside)
+        for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) trace_pairs(first, q0, total);
+    });
+}
+
+// shade: colour of the level, reflection ray, closest hit of the next level
+template <bool kLds, bool kGeneral>
+__global__ __launch_bounds__(kBlock) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
+                                                       const int level) {
+    __shared__ int s_wcnt[kBlock / 64];
+    __shared__ uint32_t s_out_base;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const SceneView scg = view_of(scene_blob);
+    const typename ViewSel<kLds>::type sc = ViewSel<kLds>::make(scg, p, s_dyn);
+    const mcrt_config& cfg = p.cfg;
+    const WaveSpace& ws = p.ws;
+    const int par = level & 1;
+    const int mode = shadow_mode(sc, cfg);
+    const int S = cfg.shadow_samples;
+    const int stride = ws.stack_stride;
+    const float* fb = sc.hdr->background;
+    const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
+    uint32_t* my_rng = nullptr;
+    if constexpr (kGeneral)
+        if (ws.hit_rng) my_rng = ws.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * 624;
+    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) {
+        bool next_hit = false;
+        Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
+        Hit nhit;
+        nhit.hit = false;
+        uint32_t root = 0;
+        int depth = 0;
+        if (threadIdx.x < n) {
+            const uint32_t e = first + threadIdx.x;
+            const float4 qo = ws.q_o[par][e], qd = ws.q_d[par][e], qp = ws.q_p[par][e], qn = ws.q_n[par][e],
+                         qt = ws.q_t[par][e];
+            root = __float_as_uint(qo.w);
+            depth = __float_as_int(qd.w);
+            const Ray ray{mk(qo.x, qo.y, qo.z), mk(qd.x, qd.y, qd.z)};
+            Hit hit;
+            hit.hit = true;
+            hit.outer = false;
+            hit.t = 0.0f;
+            hit.p = mk(qp.x, qp.y, qp.z);
+            hit.n = mk(qn.x, qn.y, qn.z);
+            hit.tex = C4{qt.x, qt.y, qt.z, qt.w};
+            const uint32_t lit = ws.lit[par][e];
+            const float vis =
+                (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
+            C4 c;
+            if constexpr (kGeneral)
+                c = level_color(sc, cfg, ray.o, hit, depth, vis, my_rng);
+            else
+                c = shade(sc, hit, normalize(ray.o - hit.p), vis);
+            bool done = false;
+            C4 tail = flat_bg;
+            int pushed = depth;
+            if (depth >= cfg.max_bounces) {  // no reflection: `shadedColor.a = originalAlpha; return clamp()`
+                tail = clamp4(c);
+                done = true;
+            } else {
+                ws.stack[static_cast<size_t>(root) * stride + depth] = make_float4(c.r, c.g, c.b, c.a);
+                pushed = depth + 1;
+                nray = reflect_ray(ray, hit);
+                nhit = hit_scene(sc, nray, ~0ull);
+                if (nhit.hit)
+                    next_hit = true;
+                else
+                    done = true;  // bounced ray missed → flat background (raytracer.cpp:94-102)
+            }
+            if (done) {  // unwind the recursion: fold the level colours back to front
+                for (int d = pushed - 1; d >= 0; --d) {
+                    const float4 s = ws.stack[static_cast<size_t>(root) * stride + d];
+                    tail = fold_reflection(C4{s.x, s.y, s.z, s.w}, tail);
+                }
+                ws.scol[ws.root_sample[root]] = make_float4(tail.r, tail.g, tail.b, tail.a);
+            }
+        }
+        // survivors → dense level+1 queue: one atomic per block
+        int total = 0;
+        const int rank = block_rank(next_hit, s_wcnt, total);
+        if (total > 0) {  // uniform
+            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
+            __syncthreads();
+            if (next_hit) push_entry(ws, par ^ 1, s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, depth + 1);
+            __syncthreads();
+        }
+    });
+}
+
+// resolve: ordered per-pixel sum of the queued units' sample colours (tile_renderer.cpp:116-124)
+__global__ __launch_bounds__(kBlock) void resolve_kernel(float4* __restrict__ out_frame, const RenderParams p) {
+    const WaveSpace& ws = p.ws;
+    const mcrt_config& cfg = p.cfg;
+    const uint32_t n_units = ws.counters[kCntUnits];
+    const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
+    const float inv_spp = 1.0f / static_cast<float>(spp);
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint4 d = ws.units[u];
+        const TileGeom tg = tile_of(p, static_cast<int>(d.x));
+        const uint32_t pp0 = d.y, pp1 = d.z;
+        for (uint32_t i = pp0 + threadIdx.x; i < pp1; i += kBlock) {
+            const float4* src = ws.scol + d.w + static_cast<size_t>(i - pp0) * spp;
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int s = 0; s < spp; ++s) {
+                const float4 c = src[s];
+                acc.x += c.x;
+                acc.y += c.y;
+                acc.z += c.z;
+                acc.w += c.w;
+            }
+            const uint32_t uly = i / static_cast<uint32_t>(tg.w);
+            const int ly = static_cast<int>(uly);
+            const int lx = static_cast<int>(i - uly * static_cast<uint32_t>(tg.w));
+            const int row = (p.layout == MCRT_LAYOUT_PACKED) ? (tg.owned_row * cfg.tile_size + ly) : (tg.y + ly);
+            out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
+                make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -585,21 +844,6 @@ __global__ void probe_detmath_range_kernel(int op, uint32_t lo_bits, uint64_t co
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-hipError_t read_phase_stamps(unsigned long long out[16], bool reset) {
-#ifdef MCRT_STAMPS
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) {
-        unsigned long long z[16] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z);
-    }
-    return e;
-#else
-    for (int i = 0; i < 16; ++i) out[i] = 0;
-    (void)reset;
-    return hipErrorNotSupported;
-#endif
-}
-
 Shard make_shard(const mcrt_config& cfg, int first, int step) {
     Shard s{};
     s.first = first;
@@ -612,76 +856,109 @@ Shard make_shard(const mcrt_config& cfg, int first, int step) {
 }
 
 static int owned_tiles(const RenderParams& p) { return p.shard.owned_rows * p.shard.tiles_x; }
+static bool soft_sampling(const mcrt_config& c) { return c.soft_shadows && c.shadow_samples > 1; }
 
-// rare features that need the general kernel variant
-static bool needs_general_variant(const RenderParams& p) {
-    const bool soft = p.cfg.soft_shadows && p.cfg.shadow_samples > 1;
-    return p.cfg.ao_enabled || (soft && 2 * p.cfg.shadow_samples > kMtShortMax) || p.cfg.max_bounces > kMaxStack ||
-           (soft && 2 * p.cfg.shadow_samples > p.lds_draw_floats) || p.scene_in_lds == 0;
+// rare features that need the general kernel variants (long per-hit RNG streams, AO)
+static bool needs_general_variant(const mcrt_config& c) {
+    return c.ao_enabled || (soft_sampling(c) && 2 * c.shadow_samples > kMtShortMax);
 }
 
-// Work units per tile: enough units to keep ~8 workgroups per CU in the queue even when only a
-// few tiles carry the character, but never finer than one 256-item chunk.  Units of one tile
-// share its RNG stream; a later unit catches up by twisting from the seeded state, which costs
-// (tile draws / 624) twists at worst — small next to a chunk that contains hits.
-int choose_parts_per_tile(const mcrt_config& cfg, int n_tiles, int target_units) {
-    if (n_tiles <= 0) return 1;
+// Parts of a tile that meshes can touch: one 256-sample chunk each, at most 16 — fine enough that
+// the few tiles holding the character spread over the chip.  Parts of one tile share its RNG
+// stream; a later part catches up by twisting from the seeded state (tile draws / 624 twists at
+// worst), cheap next to the rays of a touched tile.  Background tiles are never split.
+static int choose_parts_per_tile(const mcrt_config& cfg) {
     const long long spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const long long tile_items = static_cast<long long>(cfg.tile_size) * cfg.tile_size * spp;
-    const long long chunks = (tile_items + kChunk - 1) / kChunk;
-    long long parts = (target_units + n_tiles - 1) / n_tiles;
-    if (parts > chunks) parts = chunks;
-    if (parts > 4096) parts = 4096;
+    long long parts = (tile_items + kChunk - 1) / kChunk;
+    if (parts > 16) parts = 16;
     if (parts < 1) parts = 1;
     return static_cast<int>(parts);
 }
 
-void fill_launch_geometry(RenderParams& p, int target_units) {
-    const int n = owned_tiles(p);
-    p.parts_per_tile = choose_parts_per_tile(p.cfg, n, target_units);
-    const bool soft = p.cfg.soft_shadows && p.cfg.shadow_samples > 1;
-    const long long want = soft ? static_cast<long long>(kChunk) * 2 * p.cfg.shadow_samples : 0;
-    p.lds_draw_floats = static_cast<int>(want < kDrawCap ? want : kDrawCap);
-    p.grid_blocks = render_grid_blocks(p);
+WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_bytes) {
+    WorkspaceBytes w{};
+    const mcrt_config& c = p.cfg;
+    const int n_tiles = owned_tiles(p);
+    (void)target_units;
+    p.parts_per_tile = choose_parts_per_tile(c);
+    p.ws.stack_stride = c.max_bounces > 1 ? c.max_bounces : 1;
+    const size_t spp = c.samples_per_pixel > 1 ? c.samples_per_pixel : 1;
+    // slots of one tile row: every tile owns tile_size^2 * spp slots, clipped edge tiles included
+    const size_t row_samples = static_cast<size_t>(c.tile_size) * c.tile_size * static_cast<size_t>(p.shard.tiles_x) * spp;
+    const size_t S = soft_sampling(c) ? static_cast<size_t>(c.shadow_samples) : 0;
+    // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
+    const size_t per_entry = 16 + 2 * 5 * 16 + 8 * S + 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
+    size_t rows = budget_bytes / (per_entry * (row_samples ? row_samples : 1));
+    if (rows < 1) rows = 1;
+    if (rows > static_cast<size_t>(p.shard.owned_rows)) rows = p.shard.owned_rows > 0 ? p.shard.owned_rows : 1;
+    p.rows_per_batch = static_cast<int>(rows);
+    const size_t cap = rows * row_samples;
+    p.ws.cap = static_cast<uint32_t>(cap > 0xfffffff0ull ? 0xfffffff0ull : cap);
+    w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 : 0;
+    w.scol = cap * 16;
+    p.ws.unit_cap = static_cast<uint32_t>(rows * p.shard.tiles_x * p.parts_per_tile);
+    w.units = static_cast<size_t>(p.ws.unit_cap) * 16;
+    w.unit_hits = static_cast<size_t>(p.ws.unit_cap) * 4;
+    w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
+    w.queue_each = cap * 16;
+    w.draws = cap * 8 * S;
+    w.lit = cap * 4;
+    w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
+    w.root_sample = cap * 4;
+    w.counters = static_cast<size_t>(kCounterWords) * 4;
+    const bool long_rng = (soft_sampling(c) && 2 * c.shadow_samples > kMtShortMax) || (c.ao_enabled && 2 * c.ao_samples > kMtShortMax);
+    w.hit_rng = long_rng ? static_cast<size_t>(256) * kBlock * 624 * 4 : 0;  // general grids are capped at 256 WGs
+    return w;
 }
 
-int render_grid_blocks(const RenderParams& p) {
-    int n = owned_tiles(p) * (p.parts_per_tile > 0 ? p.parts_per_tile : 1);
-    // long per-hit RNG streams / very deep recursion need per-thread HBM slices: bound the grid
-    if (2 * p.cfg.shadow_samples > kMtShortMax || (p.cfg.ao_enabled && 2 * p.cfg.ao_samples > kMtShortMax) ||
-        p.cfg.max_bounces > kMaxStack)
-        return n < 1024 ? n : 1024;
-    return n;
-}
-size_t tile_rng_bytes(const RenderParams& p) {
-    return p.draws_per_sample > 0 ? static_cast<size_t>(owned_tiles(p)) * 624 * 4 : 0;
-}
-size_t hit_rng_bytes(const RenderParams& p) {
-    bool need = (p.cfg.soft_shadows && 2 * p.cfg.shadow_samples > kMtShortMax) ||
-                (p.cfg.ao_enabled && 2 * p.cfg.ao_samples > kMtShortMax);
-    return need ? static_cast<size_t>(render_grid_blocks(p)) * kBlock * 624 * 4 : 0;
-}
-size_t deep_stack_bytes(const RenderParams& p) {
-    return p.cfg.max_bounces > kMaxStack
-               ? static_cast<size_t>(render_grid_blocks(p)) * kBlock * p.cfg.max_bounces * 16
-               : 0;
+template <bool kLds>
+static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn) {
+    const mcrt_config& c = p.cfg;
+    const bool general = needs_general_variant(c);
+    const bool soft = soft_sampling(c);
+    const int levels = c.max_bounces < 0 ? 0 : c.max_bounces + 1;
+    const int grid = general ? 256 : kQueueGrid;
+    for (int L = 0; L < levels; ++L) {
+        if (soft) {
+            if (general)
+                hipLaunchKernelGGL(mt_draws_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p, L);
+            else
+                hipLaunchKernelGGL(mt_draws_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p, L);
+        }
+        hipLaunchKernelGGL(shadow_kernel<kLds>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+        if (general)
+            hipLaunchKernelGGL((shade_kernel<kLds, true>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+        else
+            hipLaunchKernelGGL((shade_kernel<kLds, false>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+    }
 }
 
 hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t ev_k0, hipEvent_t ev_k1) {
-    int n = owned_tiles(p);
+    const int n = owned_tiles(p);
     if (n <= 0) return hipSuccess;
-    if (p.draws_per_sample > 0) {
-        hipLaunchKernelGGL(seed_tiles_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
-    }
+    if (p.draws_per_sample > 0) hipLaunchKernelGGL(seed_tiles_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
     if (ev_k0) (void)hipEventRecord(ev_k0, stream);
-    const size_t dyn = static_cast<size_t>(p.lds_draw_floats) * 4 + static_cast<size_t>(p.lds_face_entries) * 16 +
-                       static_cast<size_t>(p.lds_alpha_words) * 4;
-    if (needs_general_variant(p))
-        hipLaunchKernelGGL(render_units_kernel<true>, dim3(p.grid_blocks), dim3(kBlock), dyn, stream, p.scene, p.tile_rng,
-                           reinterpret_cast<float4*>(p.out), p, n * p.parts_per_tile);
-    else
-        hipLaunchKernelGGL(render_units_kernel<false>, dim3(p.grid_blocks), dim3(kBlock), dyn, stream, p.scene, p.tile_rng,
-                           reinterpret_cast<float4*>(p.out), p, n * p.parts_per_tile);
+    const size_t dyn = p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_alpha_words) * 4 : 0;
+    float4* out = reinterpret_cast<float4*>(p.out);
+    for (int r0 = 0; r0 < p.shard.owned_rows; r0 += p.rows_per_batch) {
+        const int rows = p.rows_per_batch < p.shard.owned_rows - r0 ? p.rows_per_batch : p.shard.owned_rows - r0;
+        const int tile_base = r0 * p.shard.tiles_x;
+        const int batch_tiles = rows * p.shard.tiles_x;
+        hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords) * 4, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(plan_units_kernel, dim3(batch_tiles), dim3(64), 0, stream, p.scene, p, tile_base, batch_tiles);
+        const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
+        if (p.scene_in_lds) {
+            hipLaunchKernelGGL(primary_kernel<true>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            launch_levels<true>(p, stream, dyn);
+        } else {
+            hipLaunchKernelGGL(primary_kernel<false>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            launch_levels<false>(p, stream, 0);
+        }
+        const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
+        hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, out, p);
+    }
     if (ev_k1) (void)hipEventRecord(ev_k1, stream);
     return hipGetLastError();
 }

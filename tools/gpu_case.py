@@ -23,17 +23,3 @@ frame = torch.empty((cfg.height, cfg.width, 4), dtype=torch.float32, device="cud
 r, k = ds.time_render_device(cfg, frame.data_ptr(), iters)
 print(name, "render_ms", round(r, 4), "trace_kernel_ms", round(k, 4))
 
-import ctypes as C
-from minecraftskin_raytracer_amd import _lib
-lib = _lib.load()
-if hasattr(lib, "mcrt_debug_phase_stamps"):
-    arr = (C.c_uint64 * 16)()
-    lib.mcrt_debug_phase_stamps(arr, 1)           # reset
-    ds.time_render_device(cfg, frame.data_ptr(), 1)
-    if lib.mcrt_debug_phase_stamps(arr, 1) == 0:
-        names = ["prologue+setup", "stream fill", "P primary", "compaction+barrier", "B mt draws", "barrier after B", "C shadow rays",
-                 "barrier after C", "D shade/reflect", "A accumulate"]
-        tot = sum(arr[i] for i in range(10)) or 1
-        for i, nme in enumerate(names):
-            print(f"  {nme:22s} {arr[i]/1e6:10.2f} Mcycles  {100*arr[i]/tot:5.1f}%")
-        print(f"  total wave-cycles {tot/1e6:.1f} M")
