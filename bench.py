@@ -80,6 +80,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="1080p_b4_spp4_S64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 logic where RCCL cannot run (gathers through host memory)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares bit-for-bit")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,11 +102,16 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     w, h, bounces, spp, skin, pose = WORKLOADS[args.workload]
     cfg = M.Config(width=w, height=h, maxBounces=bounces, samplesPerPixel=spp)
@@ -130,10 +139,25 @@ def main() -> None:
                 for r in range(world):
                     M.unpack_rows_device(cfg, r, world, gathered[k & 1][r].data_ptr(), frame.data_ptr(), stream)
 
+        host_gather = args.dist_backend == "gloo"
+
+        class _Done:
+            def wait(self):
+                return None
+
         def step(k: int) -> None:
             buf = packed[k & 1]
             scene.render_device(cfg, buf.data_ptr(), rank, world, abi.LAYOUT_PACKED, stream)
-            work = dist.gather(buf, gathered[k & 1] if rank == 0 else None, dst=0, async_op=True)
+            if host_gather:  # rehearsal path: same sharding/unpack logic, collective through host memory
+                cpu = buf.cpu()
+                outs = [torch.empty_like(cpu) for _ in range(world)] if rank == 0 else None
+                dist.gather(cpu, outs, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[k & 1][r].copy_(outs[r])
+                work = _Done()
+            else:
+                work = dist.gather(buf, gathered[k & 1] if rank == 0 else None, dst=0, async_op=True)
             if pending:
                 finish(*pending.pop())
             pending.append((k, work))
@@ -159,7 +183,7 @@ def main() -> None:
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -169,6 +193,13 @@ def main() -> None:
     target = frame if world == 1 else packed[0]
     render_ms, trace_ms = scene.time_render_device(cfg, target.data_ptr(), max(5, min(args.steps, 50)), first, stepn, layout, stream)
     torch.cuda.synchronize()
+
+    check = None
+    if args.check and rank == 0:
+        whole = torch.empty_like(frame)
+        scene.render_device(cfg, whole.data_ptr(), 0, 1, abi.LAYOUT_FRAME, stream)
+        torch.cuda.synchronize()
+        check = bool(torch.equal(whole, frame))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -202,7 +233,8 @@ def main() -> None:
                 "name": args.workload,
                 "parallelism": "single GPU" if world == 1 else f"cyclic tile rows over {world} GPUs + RCCL gather to rank 0 (overlapped)",
             },
-            "kernel": {"trace_kernel_ms": round(trace_ms, 4), "render_ms_all_kernels": round(render_ms, 4)},
+            "kernel": {"pipeline_ms": round(trace_ms, 4), "render_ms_with_seed_prepass": round(render_ms, 4),
+                       "note": "wavefront pipeline (plan, primary, [mt_draws, shadow, shade] x levels, resolve); per-kernel split: profiles/"},
             "roofline": {
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
@@ -210,9 +242,12 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "note": "algorithmic bytes = 16 B x output pixels per launch; the path is VALU-bound by construction (DESIGN.md)",
+                "kernel": "whole wavefront pipeline of one frame (dominant stage: shadow_kernel, see profiles/)",
+                "note": "algorithmic bytes = 16 B x output pixels per frame; the path is VALU/latency-bound by construction (DESIGN.md)",
             },
         }
+        if check is not None:
+            line["check_assembled_frame_equals_single_gpu_render"] = check
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload)

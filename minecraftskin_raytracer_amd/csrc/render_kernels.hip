@@ -154,11 +154,16 @@ __device__ __forceinline__ bool mesh_touches_tile(const FlatMesh& m, const TileG
 struct LdsTables {
     const MCRT_LDS uint32_t* abits;
     const MCRT_LDS int* faces;
+    const MCRT_LDS float* mtab;
 };
-// dyn = dynamic LDS base; layout [face table: 4 ints per (mesh, face)][alpha words].  Collective.
+// dyn = dynamic LDS base; layout [face table: 4 ints per (mesh, face)][mesh table: kMeshTabWords per
+// mesh][alpha words].  Collective.
 __device__ __forceinline__ LdsTables stage_tables(const SceneView& g, const RenderParams& p, unsigned char* dyn) {
     int* s_faces = reinterpret_cast<int*>(dyn);
-    uint32_t* s_abits = reinterpret_cast<uint32_t*>(dyn + static_cast<size_t>(p.lds_face_entries) * 16);
+    float* s_mtab = reinterpret_cast<float*>(dyn + static_cast<size_t>(p.lds_face_entries) * 16);
+    const int n_meshes = p.lds_face_entries / 6;
+    uint32_t* s_abits = reinterpret_cast<uint32_t*>(dyn + static_cast<size_t>(p.lds_face_entries) * 16 +
+                                                    static_cast<size_t>(n_meshes) * kMeshTabWords * 4);
     for (int i = threadIdx.x; i < p.lds_alpha_words; i += blockDim.x) s_abits[i] = g.abits[i];
     for (int i = threadIdx.x; i < p.lds_face_entries; i += blockDim.x) {
         const FlatMesh& fm = g.meshes[i / 6];
@@ -168,8 +173,20 @@ __device__ __forceinline__ LdsTables stage_tables(const SceneView& g, const Rend
         s_faces[4 * i + 2] = fm.tex_h[f];
         s_faces[4 * i + 3] = 0;
     }
+    for (int i = threadIdx.x; i < n_meshes; i += blockDim.x) {
+        const FlatMesh& fm = g.meshes[i];
+        float* t = s_mtab + i * kMeshTabWords;
+        t[0] = fm.lo[0], t[1] = fm.lo[1], t[2] = fm.lo[2];
+        t[3] = fm.hi[0], t[4] = fm.hi[1], t[5] = fm.hi[2];
+        t[6] = __uint_as_float(fm.flags);
+        t[7] = 0.0f;
+        t[8] = fm.pivot[0], t[9] = fm.pivot[1], t[10] = fm.pivot[2];
+        t[11] = 0.0f;
+        t[12] = fm.inv_z_cos, t[13] = fm.inv_z_sin, t[14] = fm.inv_x_cos, t[15] = fm.inv_x_sin;
+        t[16] = fm.fwd_x_cos, t[17] = fm.fwd_x_sin, t[18] = fm.fwd_z_cos, t[19] = fm.fwd_z_sin;
+    }
     __syncthreads();
-    return LdsTables{(const MCRT_LDS uint32_t*)s_abits, (const MCRT_LDS int*)s_faces};
+    return LdsTables{(const MCRT_LDS uint32_t*)s_abits, (const MCRT_LDS int*)s_faces, (const MCRT_LDS float*)s_mtab};
 }
 template <bool kLds>
 struct ViewSel;
@@ -178,7 +195,7 @@ struct ViewSel<true> {
     using type = SceneViewLds;
     static __device__ __forceinline__ type make(const SceneView& g, const RenderParams& p, unsigned char* dyn) {
         LdsTables t = stage_tables(g, p, dyn);
-        return view_with_lds(g, t.abits, t.faces);
+        return view_with_lds(g, t.abits, t.faces, t.mtab);
     }
 };
 template <>
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void mt_draws_kernel(const RenderParams p, 
     uint32_t* my_rng = nullptr;
     if constexpr (kGeneral)
         my_rng = ws.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * 624;
-    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) {
+    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (threadIdx.x >= n) return;
         const uint32_t e = first + threadIdx.x;
         const float4 hp = ws.q_p[par][e];
@@ -561,8 +578,15 @@ __global__ __launch_bounds__(kBlock) void mt_draws_kernel(const RenderParams p, 
 }
 
 // shadow: one (hit, light sample) pair per lane
+// occupancy targets of the queue kernels (measured: 5 waves/SIMD best for shadow; 6+ spills)
+#ifndef MCRT_SHADOW_WAVES
+#define MCRT_SHADOW_WAVES 5
+#endif
+#ifndef MCRT_SHADE_WAVES
+#define MCRT_SHADE_WAVES 4
+#endif
 template <bool kLds>
-__global__ __launch_bounds__(kBlock) void shadow_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
+__global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
                                                         const int level) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
@@ -578,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void shadow_kernel(const uint8_t* __restric
     const V3 lpos = ld3(sc.hdr->light_pos);
     const uint32_t lane = threadIdx.x & 63u;
     // one wave-aligned group of up to 64 consecutive (entry, sample) pairs of the range `first` .. +total
-    auto trace_pairs = [&](uint32_t first, uint32_t q0, uint32_t total) {
+    auto trace_pairs = [&](uint32_t first, uint32_t q0, uint32_t total) __attribute__((always_inline)) {
         const uint32_t q = q0 + lane;
         bool visible = false;
         uint32_t e = 0;
@@ -621,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void shadow_kernel(const uint8_t* __restric
         }
         return;
     }
-    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) {
+    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (!pow2) {
             if (threadIdx.x < n) ws.lit[par][first + threadIdx.x] = 0u;
             __syncthreads();
@@ -634,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void shadow_kernel(const uint8_t* __restric
 
 // shade: colour of the level, reflection ray, closest hit of the next level
 template <bool kLds, bool kGeneral>
-__global__ __launch_bounds__(kBlock) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
+__global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
                                                        const int level) {
     __shared__ int s_wcnt[kBlock / 64];
     __shared__ uint32_t s_out_base;
@@ -652,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void shade_kernel(const uint8_t* __restrict
     uint32_t* my_rng = nullptr;
     if constexpr (kGeneral)
         if (ws.hit_rng) my_rng = ws.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * 624;
-    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) {
+    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         bool next_hit = false;
         Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
         Hit nhit;
@@ -939,7 +963,9 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t e
     if (n <= 0) return hipSuccess;
     if (p.draws_per_sample > 0) hipLaunchKernelGGL(seed_tiles_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
     if (ev_k0) (void)hipEventRecord(ev_k0, stream);
-    const size_t dyn = p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_alpha_words) * 4 : 0;
+    const size_t dyn = p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_face_entries / 6) * kMeshTabWords * 4 +
+                                            static_cast<size_t>(p.lds_alpha_words) * 4
+                                      : 0;
     float4* out = reinterpret_cast<float4*>(p.out);
     for (int r0 = 0; r0 < p.shard.owned_rows; r0 += p.rows_per_batch) {
         const int rows = p.rows_per_batch < p.shard.owned_rows - r0 ? p.rows_per_batch : p.shard.owned_rows - r0;

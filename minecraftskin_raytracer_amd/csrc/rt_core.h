@@ -106,9 +106,11 @@ struct SceneViewLds {
     const uint32_t* abits_hbm;
     const MCRT_LDS uint32_t* abits;  // 16 texels per word
     const MCRT_LDS int* faces;       // per (mesh, face slot): {texel offset | MCRT_TEX_*, width, height, 0}
+    const MCRT_LDS float* mtab;      // per mesh kMeshTabWords words: lo hi flags . pivot . trig[8]
     int n_meshes;
     DEV SceneView global() const { return SceneView{hdr, meshes, texels, abits_hbm, n_meshes}; }
 };
+constexpr int kMeshTabWords = 20;
 DEV SceneView view_of(const uint8_t* blob) {
     SceneView s;
     s.hdr = reinterpret_cast<const FlatHeader*>(blob);
@@ -118,8 +120,9 @@ DEV SceneView view_of(const uint8_t* blob) {
     s.n_meshes = static_cast<int>(s.hdr->n_meshes);
     return s;
 }
-DEV SceneViewLds view_with_lds(const SceneView& g, const MCRT_LDS uint32_t* abits, const MCRT_LDS int* faces) {
-    return SceneViewLds{g.hdr, g.meshes, g.texels, g.abits, abits, faces, g.n_meshes};
+DEV SceneViewLds view_with_lds(const SceneView& g, const MCRT_LDS uint32_t* abits, const MCRT_LDS int* faces,
+                               const MCRT_LDS float* mtab) {
+    return SceneViewLds{g.hdr, g.meshes, g.texels, g.abits, abits, faces, mtab, g.n_meshes};
 }
 
 DEVCALL float dev_sinf(float x) { return mcrt_sinf(x); }
@@ -245,12 +248,13 @@ DEV RayQ prepare(const Ray& r) {
 // texel reference of a face at (u,v): pool index, or MCRT_TEX_NULL / MCRT_TEX_EMPTY
 // (TextureRegion::sample, texture_region.h:19-26)
 template <class SV>
-DEV int face_texel_index(const SV& sc, const FlatMesh& m, int mesh_index, int face, float u, float v) {
+DEV int face_texel_index(const SV& sc, int mesh_index, int face, float u, float v) {
     int off, w, h;
     if constexpr (SV::kLds) {
         const MCRT_LDS int* f = sc.faces + (mesh_index * 6 + face) * 4;
         off = f[0], w = f[1], h = f[2];
     } else {
+        const FlatMesh& m = sc.meshes[mesh_index];
         off = m.tex_off[face], w = m.tex_w[face], h = m.tex_h[face];
     }
     if (off < 0) return off;
@@ -376,9 +380,85 @@ DEV V3 spin(V3 p, V3 pivot, bool ax, float cx, float sx, bool az, float cz, floa
     }
     return q + pivot;
 }
-DEV V3 to_world(const FlatMesh& m, V3 p, V3 pivot) {
-    return spin(p, pivot, (m.flags & MESH_APPLY_X) != 0, m.fwd_x_cos, m.fwd_x_sin, (m.flags & MESH_APPLY_Z) != 0,
+// The per-mesh data a ray test reads, in registers
+struct MeshData {
+    V3 lo, hi, pivot;
+    uint32_t flags;
+    float inv_z_cos, inv_z_sin, inv_x_cos, inv_x_sin, fwd_x_cos, fwd_x_sin, fwd_z_cos, fwd_z_sin;
+};
+// wave-uniform mesh index → scalar loads from the blob
+template <class SV>
+DEV MeshData mesh_uniform(const SV& sc, int i) {
+    const FlatMesh& m = sc.meshes[i];
+    return MeshData{ld3(m.lo),   ld3(m.hi),   ld3(m.pivot), m.flags,     m.inv_z_cos, m.inv_z_sin,
+                    m.inv_x_cos, m.inv_x_sin, m.fwd_x_cos,  m.fwd_x_sin, m.fwd_z_cos, m.fwd_z_sin};
+}
+// per-lane mesh index → the LDS mesh table (trace kernels) or vector loads from the blob
+template <class SV>
+DEV MeshData mesh_lane(const SV& sc, int i) {
+    if constexpr (SV::kLds) {
+        const MCRT_LDS float* t = sc.mtab + i * kMeshTabWords;
+        MeshData d;
+        d.lo = mk(t[0], t[1], t[2]);
+        d.hi = mk(t[3], t[4], t[5]);
+        d.flags = __float_as_uint(t[6]);
+        d.pivot = mk(t[8], t[9], t[10]);
+        d.inv_z_cos = t[12], d.inv_z_sin = t[13], d.inv_x_cos = t[14], d.inv_x_sin = t[15];
+        d.fwd_x_cos = t[16], d.fwd_x_sin = t[17], d.fwd_z_cos = t[18], d.fwd_z_sin = t[19];
+        return d;
+    } else {
+        return mesh_uniform(sc, i);
+    }
+}
+
+DEV V3 to_world(const MeshData& m, V3 p) {
+    return spin(p, m.pivot, (m.flags & MESH_APPLY_X) != 0, m.fwd_x_cos, m.fwd_x_sin, (m.flags & MESH_APPLY_Z) != 0,
                 m.fwd_z_cos, m.fwd_z_sin);
+}
+// the world-space ray in the posed mesh's local frame (intersection.cpp:384-393)
+DEV RayQ to_local(const MeshData& m, const RayQ& world) {
+    const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
+    const V3 zero = mk(0.0f, 0.0f, 0.0f);
+    V3 o = spin(world.o, m.pivot, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
+    o = spin(o, m.pivot, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
+    V3 d = spin(world.d, zero, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
+    d = spin(d, zero, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
+    return prepare(Ray{o, normalize(d)});
+}
+
+// Phase 1 of a scene query: can this mesh matter at all?  Same slab arithmetic as slab_test without
+// the face bookkeeping: overlap (:221-250), the entry/exit distance (:254-259) and — for un-posed
+// meshes, whose local t is the reported t — the distance limit.
+DEV void quick_axis(bool& ok, float& tmin, float& tmax, bool par, float o, float inv, float l, float h) {
+    if (par) {
+        if (o < l || o > h) ok = false;
+        return;
+    }
+    const float t0 = (l - o) * inv, t1 = (h - o) * inv;
+    const bool swapped = t0 > t1;
+    const float tn = swapped ? t1 : t0, tf = swapped ? t0 : t1;
+    if (tn > tmin) tmin = tn;
+    tmax = smin(tmax, tf);
+    if (tmin > tmax || tmax < 0.0f) ok = false;
+}
+DEV bool mesh_may_hit(const MeshData& m, const RayQ& world, float t_limit) {
+    if (m.flags & MESH_EMPTY) return false;
+    const bool rotated = (m.flags & MESH_ROTATED) != 0;
+    RayQ r = world;
+    if (rotated) r = to_local(m, world);
+    bool ok = true;
+    float tmin = -kFltMax, tmax = kFltMax;
+    quick_axis(ok, tmin, tmax, r.px, r.o.x, r.inv.x, m.lo.x, m.hi.x);
+    quick_axis(ok, tmin, tmax, r.py, r.o.y, r.inv.y, m.lo.y, m.hi.y);
+    quick_axis(ok, tmin, tmax, r.pz, r.o.z, r.inv.z, m.lo.z, m.hi.z);
+    if (!ok) return false;
+    float tHit = tmin;
+    if (tHit < 0.0f) {
+        tHit = tmax;
+        if (tHit < 0.0f) return false;
+    }
+    if (!rotated && !(tHit < t_limit)) return false;
+    return true;
 }
 
 // What a mesh contributes to a ray query: intersectMesh (:373-406) over intersectAABB (:200-371)
@@ -392,23 +472,14 @@ struct Cand {
     bool back;  // outer-layer exit face: normal flipped, isOuterLayer forced (:349-357)
 };
 
-// Returns true when the mesh yields a hit with t < t_limit.
+// Phase 2: full evaluation of one mesh.  Returns true when it yields a hit with t < t_limit.
 template <class SV>
-DEV bool mesh_candidate(const SV& sc, const FlatMesh& m, int mesh_index, const RayQ& world, float t_limit, Cand& c) {
+DEV bool mesh_candidate(const SV& sc, const MeshData& m, int mesh_index, const RayQ& world, float t_limit, Cand& c) {
     if (m.flags & MESH_EMPTY) return false;
     const bool rotated = (m.flags & MESH_ROTATED) != 0;
-    const V3 lo = ld3(m.lo), hi = ld3(m.hi);
-    const V3 pivot = ld3(m.pivot);
+    const V3 lo = m.lo, hi = m.hi;
     RayQ local = world;
-    if (rotated) {
-        const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
-        const V3 zero = mk(0.0f, 0.0f, 0.0f);
-        V3 o = spin(world.o, pivot, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
-        o = spin(o, pivot, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
-        V3 d = spin(world.d, zero, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
-        d = spin(d, zero, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
-        local = prepare(Ray{o, normalize(d)});
-    }
+    if (rotated) local = to_local(m, world);
     const Slab s = slab_test(local, lo, hi);
     if (!s.overlap) return false;
 
@@ -428,12 +499,12 @@ DEV bool mesh_candidate(const SV& sc, const FlatMesh& m, int mesh_index, const R
     float t_front = tHit;
     V3 p_front = hp;
     if (rotated) {
-        p_front = to_world(m, hp, pivot);
+        p_front = to_world(m, hp);
         t_front = dot(p_front - world.o, world.d);  // :402
     }
     float u, v;
     face_uv(hp, lo, hi, axis, neg, u, v);
-    int texel = face_texel_index(sc, m, mesh_index, face_slot(axis, neg), u, v);
+    int texel = face_texel_index(sc, mesh_index, face_slot(axis, neg), u, v);
     if (!(alpha_bits(sc, texel) & 1u)) {  // texColor.a != 0 → ordinary hit
         if (!(t_front < t_limit)) return false;
         c.t = t_front;
@@ -450,12 +521,12 @@ DEV bool mesh_candidate(const SV& sc, const FlatMesh& m, int mesh_index, const R
     V3 bp = local.o + local.d * s.tmax;
     float bu, bv;
     face_uv(bp, lo, hi, s.out_axis, s.out_neg, bu, bv);
-    int btexel = face_texel_index(sc, m, mesh_index, face_slot(s.out_axis, s.out_neg), bu, bv);
+    int btexel = face_texel_index(sc, mesh_index, face_slot(s.out_axis, s.out_neg), bu, bv);
     if (!(alpha_bits(sc, btexel) & 2u)) return false;  // backTexColor.a > 0
     float t_back = s.tmax;
     V3 p_back = bp;
     if (rotated) {
-        p_back = to_world(m, bp, pivot);
+        p_back = to_world(m, bp);
         t_back = dot(p_back - world.o, world.d);
     }
     if (!(t_back < t_limit)) return false;
@@ -466,6 +537,19 @@ DEV bool mesh_candidate(const SV& sc, const FlatMesh& m, int mesh_index, const R
     c.neg = s.out_neg;
     c.back = true;
     return true;
+}
+
+// Phase 1 over the scene: bit i of the result = mesh i (< 64) passed mesh_may_hit.  The loop index
+// is wave-uniform (scalar loads); meshes beyond 63 are handled by the callers' tail loops.
+template <class SV>
+DEV unsigned long long scene_candidates(const SV& sc, const RayQ& q, unsigned long long mesh_mask, float t_limit) {
+    unsigned long long cand = 0ull;
+    const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
+    for (int i = 0; i < n; ++i) {
+        if (!((mesh_mask >> i) & 1ull)) continue;  // uniform: the mask is per tile
+        if (mesh_may_hit(mesh_uniform(sc, i), q, t_limit)) cand |= 1ull << i;
+    }
+    return cand;
 }
 
 // intersectScene :408-421.  mesh_mask: bit i set → mesh i is tested (primary-ray culling; all
@@ -481,10 +565,20 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
     best.neg = false;
     best.back = false;
     int best_mesh = -1;
-    for (int i = 0; i < sc.n_meshes; ++i) {
-        if (i < 64 && !((mesh_mask >> i) & 1ull)) continue;
+    // per lane: ascending mesh index, strictly smaller t wins → first mesh on ties, like the reference
+    unsigned long long cand = scene_candidates(sc, q, mesh_mask, kFltMax);
+    while (cand) {
+        const int i = __builtin_ctzll(cand);
+        cand &= cand - 1ull;
         Cand c;
-        if (mesh_candidate(sc, sc.meshes[i], i, q, best.t, c)) {  // strictly smaller t wins, first mesh on ties
+        if (mesh_candidate(sc, mesh_lane(sc, i), i, q, best.t, c)) {
+            best = c;
+            best_mesh = i;
+        }
+    }
+    for (int i = 64; i < sc.n_meshes; ++i) {
+        Cand c;
+        if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, best.t, c)) {
             best = c;
             best_mesh = i;
         }
@@ -497,7 +591,7 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
     h.n = mk(0, 0, 0);
     h.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
     if (h.hit) {
-        const FlatMesh& m = sc.meshes[best_mesh];
+        const MeshData m = mesh_lane(sc, best_mesh);
         V3 n = face_normal(best.axis, best.neg);
         if (best.back) n = n * -1.0f;  // :354
         if (m.flags & MESH_ROTATED) {  // :400
@@ -512,18 +606,24 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
 }
 
 // "hit && t < limit" over the scene without keeping the hit: isInShadow :25 and computeAO :72.
-// The reference finds the closest hit first; min t < limit ⇔ some t < limit, so the scan stops at
-// the first mesh that qualifies.
+// The reference finds the closest hit first; min t < limit ⇔ some t < limit, so a lane stops at
+// its first qualifying mesh.
 template <class SV>
 DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
     const RayQ q = prepare(r);
-    for (int i = 0; i < sc.n_meshes; ++i) {
+    unsigned long long cand = scene_candidates(sc, q, ~0ull, limit);
+    while (cand) {
+        const int i = __builtin_ctzll(cand);
+        cand &= cand - 1ull;
         Cand c;
-        if (mesh_candidate(sc, sc.meshes[i], i, q, limit, c)) return true;
+        if (mesh_candidate(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
+    }
+    for (int i = 64; i < sc.n_meshes; ++i) {
+        Cand c;
+        if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
     }
     return false;
 }
-
 // shared copy for the rare sequential paths (AO, very long shadow streams, probes)
 DEVCALL bool any_hit_call(SceneView sc, Ray r, float limit) { return any_hit_inline(sc, r, limit); }
 template <class SV>
@@ -564,7 +664,8 @@ DEV V3 light_sample_position(const SV& sc, V3 point, float d0, float d1) {
     V3 bitangent = cross(toPoint, tangent);
     float angle = kTwoPi * d0;
     float rr = sc.hdr->light_radius * __builtin_sqrtf(d1);
-    V3 off = tangent * (rr * dev_cosf(angle)) + bitangent * (rr * dev_sinf(angle));
+    // inlined libm kernels: a call here makes the shadow kernel spill its live ray state around it
+    V3 off = tangent * (rr * mcrt_cosf(angle)) + bitangent * (rr * mcrt_sinf(angle));
     return lpos + off;
 }
 template <class SV>

@@ -146,3 +146,33 @@ def test_device_quantiser_matches_host(mcrt, north_star):
     mcrt.quantize_rgba8_device(frame.data_ptr(), q.data_ptr(), cfg.width * cfg.height, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(q.cpu().numpy(), mcrt.quantize_rgba8(frame.cpu().numpy()))
+
+
+def test_multi_batch_render_matches_single_batch(mcrt, gpu, tmp_path):
+    """A tiny workspace budget forces the wavefront pipeline to cut the frame into many batches of
+    tile rows; the image must not change.  (The budget is read once per process → subprocess.)"""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "render_small_budget.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.abspath(__file__)))})\n"
+        "import minecraftskin_raytracer_amd as M, scenes\n"
+        "cfg = M.Config(width=320, height=200, maxBounces=3, samplesPerPixel=4)\n"
+        "img = M.TileRenderer.render(scenes.skin_scene('S64', 6), cfg)\n"
+        "assert M.TileRenderer.lastErrors() == []\n"
+        "np.save(sys.argv[1], img)\n")
+    out_small, out_big = str(tmp_path / "small.npy"), str(tmp_path / "big.npy")
+    env = dict(os.environ, MCRT_WORKSPACE_MB="8")  # ~2 tile rows per batch at this size
+    subprocess.check_call([sys.executable, str(script), out_small], env=env)
+    subprocess.check_call([sys.executable, str(script), out_big])
+    a, b = np.load(out_small), np.load(out_big)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    import oraclelib
+    cfg = abi.Config(width=320, height=200, maxBounces=3, samplesPerPixel=4)
+    sd = scenes.skin_scene("S64", 6)  # keep the description alive while the oracle reads it
+    ref = oraclelib.Oracle().render(sd.ptr, cfg)
+    scenes.assert_bit_equal(a, ref, "multi-batch render vs oracle")
