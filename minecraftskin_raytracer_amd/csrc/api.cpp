@@ -93,7 +93,7 @@ struct mcrt_scene {
     uint32_t n_meshes = 0;
     DeviceBuffer blob;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
-    DeviceBuffer tile_rng, scol, units, unit_hits[2], tile_mask, queues[10], draws, lit[2], stack, root_sample, counters, hit_rng;
+    DeviceBuffer tile_rng, scol, units, unit_hits[2], tile_mask, queues[10], targets, lit[2], stack, root_sample, counters, hit_rng;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -131,7 +131,7 @@ int prepare(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layo
     HIP_TRY(s->unit_hits[0].reserve(w.unit_hits));
     HIP_TRY(s->unit_hits[1].reserve(w.unit_hits));
     for (auto& q : s->queues) HIP_TRY(q.reserve(w.queue_each));
-    HIP_TRY(s->draws.reserve(w.draws));
+    HIP_TRY(s->targets.reserve(w.targets));
     HIP_TRY(s->lit[0].reserve(w.lit));
     HIP_TRY(s->lit[1].reserve(w.lit));
     HIP_TRY(s->stack.reserve(w.stack));
@@ -150,7 +150,7 @@ int prepare(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layo
         ws.q_n[k] = static_cast<float4*>(s->queues[6 + k].ptr);
         ws.q_t[k] = static_cast<float4*>(s->queues[8 + k].ptr);
     }
-    ws.draws = static_cast<float*>(s->draws.ptr);
+    ws.targets = static_cast<float*>(s->targets.ptr);
     ws.lit[0] = static_cast<uint32_t*>(s->lit[0].ptr);
     ws.lit[1] = static_cast<uint32_t*>(s->lit[1].ptr);
     ws.unit_hits[0] = static_cast<uint32_t*>(s->unit_hits[0].ptr);

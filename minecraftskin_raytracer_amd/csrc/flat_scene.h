@@ -27,7 +27,7 @@ enum : uint32_t {
 #define MCRT_TEX_NULL (-1)  /* Triangle::texture == nullptr → opaque magenta (intersection.cpp:305) */
 #define MCRT_TEX_EMPTY (-2) /* width/height <= 0 or no pixels → Color() (texture_region.h:20-22) */
 
-struct FlatMesh {  // 160 bytes
+struct FlatMesh {  // 176 bytes
     float lo[3];
     float hi[3];
     float pivot[3];
@@ -45,6 +45,9 @@ struct FlatMesh {  // 160 bytes
     // conservative screen-space bound of the mesh for primary-ray culling, in pixels of a
     // normalised [0,1]x[0,1] image (u0,v0,u1,v1); u0 > u1 means "never cull"
     float screen[4];
+    // world-space bounding sphere (centre, padded radius) — a conservative pre-test for posed meshes,
+    // whose exact test needs the ray in the mesh's local frame
+    float sphere[4];
 };
 
 struct FlatHeader {  // 192 bytes
@@ -73,7 +76,7 @@ struct FlatHeader {  // 192 bytes
     uint32_t pad2[11];
 };
 
-static_assert(sizeof(FlatMesh) == 160, "FlatMesh layout");
+static_assert(sizeof(FlatMesh) == 176, "FlatMesh layout");
 static_assert(sizeof(FlatHeader) == 192, "FlatHeader layout");
 
 #endif

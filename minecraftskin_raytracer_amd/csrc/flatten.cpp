@@ -210,6 +210,21 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
             }
         }
 
+        // Bounding sphere in world space: centre = (posed) box centre, radius = half diagonal, padded.
+        {
+            double c[3] = {0.5 * (static_cast<double>(lo[0]) + hi[0]), 0.5 * (static_cast<double>(lo[1]) + hi[1]),
+                           0.5 * (static_cast<double>(lo[2]) + hi[2])};
+            double w[3] = {c[0], c[1], c[2]};
+            if (rotated) rotate_fwd_d(m, c, w);
+            double dx = 0.5 * (static_cast<double>(hi[0]) - lo[0]), dy = 0.5 * (static_cast<double>(hi[1]) - lo[1]),
+                   dz = 0.5 * (static_cast<double>(hi[2]) - lo[2]);
+            double r = std::sqrt(dx * dx + dy * dy + dz * dz);
+            f.sphere[0] = static_cast<float>(w[0]);
+            f.sphere[1] = static_cast<float>(w[1]);
+            f.sphere[2] = static_cast<float>(w[2]);
+            f.sphere[3] = (ntri > 0 && std::isfinite(r)) ? static_cast<float>(r * 1.01 + 0.05) : -1.0f;  // < 0: no bound
+        }
+
         // Conservative screen bound: project the 8 box corners (posed ones rotated forward) and
         // pad generously.  Only ever used to SKIP a mesh whose slab test would have missed, so it
         // must never be too small; any doubt → "never cull" (u0 > u1).

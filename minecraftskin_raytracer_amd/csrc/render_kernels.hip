@@ -16,8 +16,9 @@
 //                                     ray, closest hit over the tile's mesh mask; misses write their
 //                                     sample colour, hits are appended to the level-0 queue
 //   per recursion level L = 0 .. maxBounces:
-//     mt_draws      1 lane / hit      register-only truncated mt19937 → 2·S shadow draws
-//     shadow        1 lane / (hit, light sample)   disk sample → any-hit shadow ray → lit count
+//     light_samples 1 lane / hit      register-only truncated mt19937 → 2·S draws → light frame and the
+//                                     S disk sample positions (cos/sin/sqrt of independent samples interleave)
+//     shadow        1 lane / (hit, light sample)   any-hit shadow ray to the sample → lit count
 //     shade         1 lane / hit      Blinn-Phong (+AO), reflection ray, closest hit → level L+1
 //                                     queue; chains that end fold their level colours back to front
 //   resolve         1 lane / pixel    ordered sum of the pixel's sample colours (float addition
@@ -184,6 +185,7 @@ __device__ __forceinline__ LdsTables stage_tables(const SceneView& g, const Rend
         t[11] = 0.0f;
         t[12] = fm.inv_z_cos, t[13] = fm.inv_z_sin, t[14] = fm.inv_x_cos, t[15] = fm.inv_x_sin;
         t[16] = fm.fwd_x_cos, t[17] = fm.fwd_x_sin, t[18] = fm.fwd_z_cos, t[19] = fm.fwd_z_sin;
+        t[20] = fm.sphere[0], t[21] = fm.sphere[1], t[22] = fm.sphere[2], t[23] = fm.sphere[3];
     }
     __syncthreads();
     return LdsTables{(const MCRT_LDS uint32_t*)s_abits, (const MCRT_LDS int*)s_faces, (const MCRT_LDS float*)s_mtab};
@@ -548,10 +550,56 @@ __device__ __forceinline__ void for_each_entry_block(const WaveSpace& ws, int le
     }
 }
 
-// mt_draws: the sequential 397-step seeding recurrence, one hit per lane; with thousands of
-// resident waves the dependent integer chain is hidden by occupancy
+// The S light sample positions of one hit: mt19937(shadow seed) → 2·S draws → disk samples
+// (shading.cpp:28-53).  kGeneral: streams longer than 227 draws use the full engine in HBM.
 template <bool kGeneral>
-__global__ __launch_bounds__(kBlock) void mt_draws_kernel(const RenderParams p, const int level) {
+struct SampleRng {
+    using type = MtShort;
+};
+template <>
+struct SampleRng<true> {
+    using type = HitRng;
+};
+
+// seeds the engine of one hit (the sequential part: the 397-step mt19937 recurrence)
+template <bool kGeneral>
+__device__ __forceinline__ void seed_light_rng(typename SampleRng<kGeneral>::type& rng, V3 P, int depth, int S, uint32_t* my_rng) {
+    if constexpr (kGeneral)
+        rng.seed(shadow_seed(P, depth), 2 * S, my_rng);
+    else
+        rng.seed(shadow_seed(P, depth));
+}
+
+// 2·S draws of a seeded engine → the S light sample positions of entry e
+template <class Rng>
+__device__ __forceinline__ void write_light_samples(const SceneView& sc, const WaveSpace& ws, uint32_t e, V3 P, int S, Rng& rng) {
+    const LightFrame frame = light_frame(sc, P);
+    float* dst = ws.targets + static_cast<size_t>(e) * 3 * S;
+    for (int i = 0; i < S; ++i) {
+        const float d0 = rng.uniform();
+        const float d1 = rng.uniform();
+        const V3 t = light_sample_on_frame(sc, frame, d0, d1);
+        dst[3 * i + 0] = t.x;
+        dst[3 * i + 1] = t.y;
+        dst[3 * i + 2] = t.z;
+    }
+}
+
+template <bool kGeneral>
+__device__ __forceinline__ void emit_light_samples(const SceneView& sc, const WaveSpace& ws, uint32_t e, V3 P, int depth, int S,
+                                                   uint32_t* my_rng) {
+    typename SampleRng<kGeneral>::type rng;
+    seed_light_rng<kGeneral>(rng, P, depth, S, my_rng);
+    write_light_samples(sc, ws, e, P, S, rng);
+}
+
+// light_samples: per hit, the 397-step mt19937 seeding recurrence (sequential), then its 2·S
+// draws turned into the S light sample positions.  One hit per lane: thousands of resident waves
+// hide the integer chain, and the S independent cos/sin/sqrt evaluations of a hit interleave.
+template <bool kGeneral>
+__global__ __launch_bounds__(kBlock) void light_samples_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
+                                                               const int level) {
+    const SceneView sc = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
     const int par = level & 1;
     const int S = p.cfg.shadow_samples;
@@ -562,18 +610,7 @@ __global__ __launch_bounds__(kBlock) void mt_draws_kernel(const RenderParams p, 
         if (threadIdx.x >= n) return;
         const uint32_t e = first + threadIdx.x;
         const float4 hp = ws.q_p[par][e];
-        const int depth = __float_as_int(ws.q_d[par][e].w);
-        const uint32_t seed = shadow_seed(mk(hp.x, hp.y, hp.z), depth);
-        float* dst = ws.draws + static_cast<size_t>(e) * 2 * S;
-        if constexpr (kGeneral) {
-            HitRng rng;
-            rng.seed(seed, 2 * S, my_rng);
-            for (int i = 0; i < 2 * S; ++i) dst[i] = rng.uniform();
-        } else {
-            MtShort rng;
-            rng.seed(seed);
-            for (int i = 0; i < 2 * S; ++i) dst[i] = rng.uniform();
-        }
+        emit_light_samples<kGeneral>(sc, ws, e, mk(hp.x, hp.y, hp.z), __float_as_int(ws.q_d[par][e].w), S, my_rng);
     });
 }
 
@@ -615,10 +652,7 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
             V3 N = mk(hn.x, hn.y, hn.z);
             if (mode == SHADOW_HARD) N = normalize(N);
             V3 target = lpos;
-            if (mode == SHADOW_SOFT) {
-                const float* dr = ws.draws + static_cast<size_t>(e) * 2 * S + 2 * j;
-                target = light_sample_position(sc, P, dr[0], dr[1]);
-            }
+            if (mode == SHADOW_SOFT) target = ld3(ws.targets + (static_cast<size_t>(e) * S + j) * 3);
             visible = !in_shadow_inline(sc, P, N, target);
         }
         if (pow2) {
@@ -733,9 +767,20 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
         int total = 0;
         const int rank = block_rank(next_hit, s_wcnt, total);
         if (total > 0) {  // uniform
-            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
+            // the append atomics of a level all hit one address and serialise (~11 ns each): issue
+            // it first and hide its queueing behind the seeding chain of the new entries' samples
+            uint32_t base = 0;
+            if (threadIdx.x == 0) base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
+            typename SampleRng<kGeneral>::type rng;
+            const bool samples = next_hit && mode == SHADOW_SOFT;
+            if (samples) seed_light_rng<kGeneral>(rng, nhit.p, depth + 1, S, my_rng);
+            if (threadIdx.x == 0) s_out_base = base;
             __syncthreads();
-            if (next_hit) push_entry(ws, par ^ 1, s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, depth + 1);
+            if (next_hit) {
+                const uint32_t ne = s_out_base + static_cast<uint32_t>(rank);
+                push_entry(ws, par ^ 1, ne, nray, nhit, root, depth + 1);
+                if (samples) write_light_samples(scg, ws, ne, nhit.p, S, rng);
+            }
             __syncthreads();
         }
     });
@@ -912,7 +957,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     const size_t row_samples = static_cast<size_t>(c.tile_size) * c.tile_size * static_cast<size_t>(p.shard.tiles_x) * spp;
     const size_t S = soft_sampling(c) ? static_cast<size_t>(c.shadow_samples) : 0;
     // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
-    const size_t per_entry = 16 + 2 * 5 * 16 + 8 * S + 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
+    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * S + 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
     size_t rows = budget_bytes / (per_entry * (row_samples ? row_samples : 1));
     if (rows < 1) rows = 1;
     if (rows > static_cast<size_t>(p.shard.owned_rows)) rows = p.shard.owned_rows > 0 ? p.shard.owned_rows : 1;
@@ -926,7 +971,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     w.unit_hits = static_cast<size_t>(p.ws.unit_cap) * 4;
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
     w.queue_each = cap * 16;
-    w.draws = cap * 8 * S;
+    w.targets = cap * 12 * S;
     w.lit = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
     w.root_sample = cap * 4;
@@ -944,11 +989,11 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
     const int levels = c.max_bounces < 0 ? 0 : c.max_bounces + 1;
     const int grid = general ? 256 : kQueueGrid;
     for (int L = 0; L < levels; ++L) {
-        if (soft) {
+        if (soft && L == 0) {  // deeper levels: `shade` emits the samples of the entries it appends
             if (general)
-                hipLaunchKernelGGL(mt_draws_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p, L);
+                hipLaunchKernelGGL(light_samples_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
             else
-                hipLaunchKernelGGL(mt_draws_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p, L);
+                hipLaunchKernelGGL(light_samples_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
         }
         hipLaunchKernelGGL(shadow_kernel<kLds>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
         if (general)

@@ -110,7 +110,7 @@ struct SceneViewLds {
     int n_meshes;
     DEV SceneView global() const { return SceneView{hdr, meshes, texels, abits_hbm, n_meshes}; }
 };
-constexpr int kMeshTabWords = 20;
+constexpr int kMeshTabWords = 24;
 DEV SceneView view_of(const uint8_t* blob) {
     SceneView s;
     s.hdr = reinterpret_cast<const FlatHeader*>(blob);
@@ -383,6 +383,8 @@ DEV V3 spin(V3 p, V3 pivot, bool ax, float cx, float sx, bool az, float cz, floa
 // The per-mesh data a ray test reads, in registers
 struct MeshData {
     V3 lo, hi, pivot;
+    V3 centre;      // world-space bounding sphere
+    float radius;   // padded; < 0 → no bound
     uint32_t flags;
     float inv_z_cos, inv_z_sin, inv_x_cos, inv_x_sin, fwd_x_cos, fwd_x_sin, fwd_z_cos, fwd_z_sin;
 };
@@ -390,8 +392,8 @@ struct MeshData {
 template <class SV>
 DEV MeshData mesh_uniform(const SV& sc, int i) {
     const FlatMesh& m = sc.meshes[i];
-    return MeshData{ld3(m.lo),   ld3(m.hi),   ld3(m.pivot), m.flags,     m.inv_z_cos, m.inv_z_sin,
-                    m.inv_x_cos, m.inv_x_sin, m.fwd_x_cos,  m.fwd_x_sin, m.fwd_z_cos, m.fwd_z_sin};
+    return MeshData{ld3(m.lo),   ld3(m.hi),   ld3(m.pivot), ld3(m.sphere), m.sphere[3], m.flags,     m.inv_z_cos,
+                    m.inv_z_sin, m.inv_x_cos, m.inv_x_sin,  m.fwd_x_cos,   m.fwd_x_sin, m.fwd_z_cos, m.fwd_z_sin};
 }
 // per-lane mesh index → the LDS mesh table (trace kernels) or vector loads from the blob
 template <class SV>
@@ -405,6 +407,8 @@ DEV MeshData mesh_lane(const SV& sc, int i) {
         d.pivot = mk(t[8], t[9], t[10]);
         d.inv_z_cos = t[12], d.inv_z_sin = t[13], d.inv_x_cos = t[14], d.inv_x_sin = t[15];
         d.fwd_x_cos = t[16], d.fwd_x_sin = t[17], d.fwd_z_cos = t[18], d.fwd_z_sin = t[19];
+        d.centre = mk(t[20], t[21], t[22]);
+        d.radius = t[23];
         return d;
     } else {
         return mesh_uniform(sc, i);
@@ -443,22 +447,31 @@ DEV void quick_axis(bool& ok, float& tmin, float& tmax, bool par, float o, float
 }
 DEV bool mesh_may_hit(const MeshData& m, const RayQ& world, float t_limit) {
     if (m.flags & MESH_EMPTY) return false;
-    const bool rotated = (m.flags & MESH_ROTATED) != 0;
-    RayQ r = world;
-    if (rotated) r = to_local(m, world);
+    if (m.flags & MESH_ROTATED) {
+        // posed mesh: the exact test needs the ray in the mesh's frame (phase 2).  Here only a
+        // conservative bounding-sphere test — every point of the posed box lies within `radius` of
+        // `centre`, so a ray that misses the padded sphere, or leaves it behind, cannot hit the box.
+        // |oc x d|^2 <= r^2 |d|^2  written without division; generous slack for float rounding.
+        if (m.radius < 0.0f) return true;
+        const V3 oc = m.centre - world.o;
+        const float dd = dot(world.d, world.d), b = dot(oc, world.d), oc2 = dot(oc, oc);
+        const float r2 = m.radius * m.radius;
+        if (oc2 * dd - b * b > r2 * dd + 1e-4f * oc2 * dd + 1e-6f) return false;
+        if (b < 0.0f && oc2 > r2 * 1.001f + 1e-3f) return false;  // sphere entirely behind the origin
+        return true;
+    }
     bool ok = true;
     float tmin = -kFltMax, tmax = kFltMax;
-    quick_axis(ok, tmin, tmax, r.px, r.o.x, r.inv.x, m.lo.x, m.hi.x);
-    quick_axis(ok, tmin, tmax, r.py, r.o.y, r.inv.y, m.lo.y, m.hi.y);
-    quick_axis(ok, tmin, tmax, r.pz, r.o.z, r.inv.z, m.lo.z, m.hi.z);
+    quick_axis(ok, tmin, tmax, world.px, world.o.x, world.inv.x, m.lo.x, m.hi.x);
+    quick_axis(ok, tmin, tmax, world.py, world.o.y, world.inv.y, m.lo.y, m.hi.y);
+    quick_axis(ok, tmin, tmax, world.pz, world.o.z, world.inv.z, m.lo.z, m.hi.z);
     if (!ok) return false;
     float tHit = tmin;
     if (tHit < 0.0f) {
         tHit = tmax;
         if (tHit < 0.0f) return false;
     }
-    if (!rotated && !(tHit < t_limit)) return false;
-    return true;
+    return tHit < t_limit;  // un-posed: local t is the reported t
 }
 
 // What a mesh contributes to a ray query: intersectMesh (:373-406) over intersectAABB (:200-371)
@@ -545,6 +558,7 @@ template <class SV>
 DEV unsigned long long scene_candidates(const SV& sc, const RayQ& q, unsigned long long mesh_mask, float t_limit) {
     unsigned long long cand = 0ull;
     const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
+#pragma unroll 1
     for (int i = 0; i < n; ++i) {
         if (!((mesh_mask >> i) & 1ull)) continue;  // uniform: the mask is per tile
         if (mesh_may_hit(mesh_uniform(sc, i), q, t_limit)) cand |= 1ull << i;
@@ -576,11 +590,13 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
             best_mesh = i;
         }
     }
-    for (int i = 64; i < sc.n_meshes; ++i) {
-        Cand c;
-        if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, best.t, c)) {
-            best = c;
-            best_mesh = i;
+    if constexpr (!SV::kLds) {  // LDS views hold at most 64 meshes
+        for (int i = 64; i < sc.n_meshes; ++i) {
+            Cand c;
+            if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, best.t, c)) {
+                best = c;
+                best_mesh = i;
+            }
         }
     }
     Hit h;
@@ -618,9 +634,11 @@ DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
         Cand c;
         if (mesh_candidate(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
     }
-    for (int i = 64; i < sc.n_meshes; ++i) {
-        Cand c;
-        if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
+    if constexpr (!SV::kLds) {
+        for (int i = 64; i < sc.n_meshes; ++i) {
+            Cand c;
+            if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
+        }
     }
     return false;
 }
@@ -654,19 +672,30 @@ DEV int shadow_mode(const SV& sc, const mcrt_config& cfg) {
     return SHADOW_HARD;
 }
 
-// one stratified-disk light sample position (shading.cpp:35-53)
+// the disk frame at the light, facing the shaded point (shading.cpp:35-41) — a function of the hit only
+struct LightFrame {
+    V3 tangent, bitangent;
+};
 template <class SV>
-DEV V3 light_sample_position(const SV& sc, V3 point, float d0, float d1) {
+DEV LightFrame light_frame(const SV& sc, V3 point) {
     V3 lpos = ld3(sc.hdr->light_pos);
     V3 toPoint = normalize(point - lpos);
     V3 tangent = (__builtin_fabsf(toPoint.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), toPoint))
                                                      : normalize(cross(mk(0, 1, 0), toPoint));
-    V3 bitangent = cross(toPoint, tangent);
+    return LightFrame{tangent, cross(toPoint, tangent)};
+}
+// one stratified-disk light sample position (shading.cpp:46-53)
+template <class SV>
+DEV V3 light_sample_on_frame(const SV& sc, const LightFrame& f, float d0, float d1) {
     float angle = kTwoPi * d0;
     float rr = sc.hdr->light_radius * __builtin_sqrtf(d1);
-    // inlined libm kernels: a call here makes the shadow kernel spill its live ray state around it
-    V3 off = tangent * (rr * mcrt_cosf(angle)) + bitangent * (rr * mcrt_sinf(angle));
-    return lpos + off;
+    // inlined libm kernels: calls here would serialise the independent samples of a hit
+    V3 off = f.tangent * (rr * mcrt_cosf(angle)) + f.bitangent * (rr * mcrt_sinf(angle));
+    return ld3(sc.hdr->light_pos) + off;
+}
+template <class SV>
+DEV V3 light_sample_position(const SV& sc, V3 point, float d0, float d1) {
+    return light_sample_on_frame(sc, light_frame(sc, point), d0, d1);
 }
 template <class SV>
 DEV bool light_sample_visible(const SV& sc, V3 point, V3 normal, float d0, float d1) {

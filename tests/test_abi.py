@@ -114,11 +114,11 @@ def test_flatten_blob_layout(mcrt):
     blob = mcrt.flatten(sd)
     hdr = np.frombuffer(blob[:16], np.uint32)
     assert hdr[0] == 0x4D435254 and hdr[1] == 12 and hdr[2] == 12 * 272  # 12 meshes, 3264 texels
-    assert len(blob) == 192 + 12 * 160 + 3264 * 16 + 3264 // 16 * 4
+    assert len(blob) == 192 + 12 * 176 + 3264 * 16 + 3264 // 16 * 4
     f = np.frombuffer(blob[:192], np.float32)
     assert np.allclose(f[12:15], [0, 18, 50]) and abs(f[15] - np.tan(np.radians(30.0))) < 1e-6  # camera pos, tan(fov/2)
     assert np.allclose(f[16:19], [0, 0, -1]) and np.allclose(f[20:23], [1, 0, 0]) and np.allclose(f[24:27], [0, 1, 0])
-    mesh0 = np.frombuffer(blob[192:192 + 160], np.float32)
+    mesh0 = np.frombuffer(blob[192:192 + 176], np.float32)
     assert np.allclose(mesh0[0:6], [-4, 24, -4, 4, 32, 4])  # head AABB (local space: the mesh is posed)
     flags = np.frombuffer(blob[192 + 68:192 + 72], np.uint32)[0]
     assert flags & 2 and flags & 4 and flags & 8 and not flags & 1  # rotated, X and Z applied, inner

@@ -126,3 +126,76 @@ def test_progress_callback_contract(mcrt, gpu):
     cfg = abi.Config(width=32, height=32, maxBounces=0, tileSize=16)
     mcrt.TileRenderer.render(mcrt.SceneDesc(scenes.simple_scene()), cfg, lambda d, t: calls.append((d, t)))
     assert [c[0] for c in calls] == [1, 2, 3, 4] and all(c[1] == 4 for c in calls)
+
+
+# ---- rarely taken kernel variants ----------------------------------------------------------------------
+VARIANT_CASES = [
+    # non-power-of-two shadow sample counts → lit counts through atomics instead of a wave ballot
+    ("S64", 6, dict(width=72, height=48, maxBounces=2, samplesPerPixel=2, shadowSamples=5)),
+    ("S64", 0, dict(width=72, height=48, maxBounces=3, samplesPerPixel=1, shadowSamples=13)),
+    # power-of-two counts other than 8, including a whole wave per hit
+    ("S64", 3, dict(width=64, height=40, maxBounces=1, samplesPerPixel=1, shadowSamples=64)),
+    ("S64", 0, dict(width=64, height=40, maxBounces=2, samplesPerPixel=2, shadowSamples=16)),
+    # per-hit RNG streams longer than 227 draws → "general" kernels with the full mt19937 engine
+    ("S64", 0, dict(width=48, height=32, maxBounces=1, samplesPerPixel=1, shadowSamples=120)),
+    ("S64", 5, dict(width=40, height=30, maxBounces=1, samplesPerPixel=1, aoEnabled=True, aoSamples=130)),
+    # deep recursion (stack stride > 16), hard shadows, point light via radius handled below
+    ("S64", 0, dict(width=48, height=48, maxBounces=20, samplesPerPixel=1, softShadows=False)),
+    # huge tile (one tile = whole frame, many parts) and tile size 1 (one pixel per tile)
+    ("S64", 6, dict(width=70, height=44, maxBounces=2, samplesPerPixel=3, tileSize=128)),
+    ("S32", 1, dict(width=24, height=20, maxBounces=1, samplesPerPixel=2, tileSize=1)),
+    # DOF with many samples (4 draws per sample), large spp → sample-per-thread background path
+    ("S64", 0, dict(width=40, height=24, maxBounces=1, samplesPerPixel=40, dofEnabled=True, aperture=0.8, focusDistance=45.0)),
+]
+
+
+@pytest.mark.parametrize("kind,pose,cfgkw", VARIANT_CASES)
+def test_render_variants_match_oracle(mcrt, gpu, oracle, kind, pose, cfgkw):
+    sd = scenes.skin_scene(kind, pose)
+    cfg = abi.Config(**cfgkw)
+    img = mcrt.TileRenderer.render(sd, cfg)
+    assert mcrt.TileRenderer.lastErrors() == []
+    scenes.assert_bit_equal(img, oracle.render(sd.ptr, cfg), f"{kind} pose {pose} {cfgkw}")
+
+
+def test_point_light_soft_shadow_degenerates(mcrt, gpu, oracle):
+    # light.radius < 1e-4 with softShadows on: computeSoftShadow falls back to one hard ray, raw normal
+    d = scenes.skin_scene("S64", 2).to_numpy()
+    sc = abi.scene_from_numpy(d)
+    sc.light_radius = 0.0
+    sd = mcrt.SceneDesc(sc)
+    cfg = abi.Config(width=64, height=48, maxBounces=2, samplesPerPixel=2)
+    scenes.assert_bit_equal(mcrt.TileRenderer.render(sd, cfg), oracle.render(sd.ptr, cfg), "point light")
+
+
+def test_scene_too_big_for_lds_tables(mcrt, gpu, oracle):
+    # > 64 meshes: the face/mesh tables do not fit the LDS budget → kernels compiled against HBM views,
+    # and meshes beyond bit 63 of the candidate mask take the tail loops
+    g = np.random.default_rng(7)
+    meshes = []
+    for i in range(70):
+        col = tuple(g.uniform(0.2, 1.0, 3)) + (1.0,)
+        pos = (float(g.uniform(-12, 12)), float(g.uniform(4, 30)), float(g.uniform(-6, 6)))
+        tex = abi.Texture(2, 2, np.array([col, col, col, (0, 0, 0, 0) if i % 3 == 0 else col], np.float32))
+        meshes.append(scenes.build_box(tex, pos, (2.0, 2.0, 2.0), 0.5 if i % 3 == 0 else 0.0))
+    sc = scenes.simple_scene(meshes, light=(0, 40, 30), cam_pos=(0, 18, 50), cam_target=(0, 18, 0), bg=(0.2, 0.3, 0.5, 1.0))
+    sd = mcrt.SceneDesc(sc)
+    cfg = abi.Config(width=96, height=64, maxBounces=3, samplesPerPixel=2)
+    scenes.assert_bit_equal(mcrt.TileRenderer.render(sd, cfg), oracle.render(sd.ptr, cfg), "70-mesh scene")
+    ds = mcrt.DeviceScene(sd)
+    rays = scenes.random_rays(2000, seed=3, target=(0.0, 18.0, 0.0), spread=14.0)
+    scenes.assert_hits_equal(ds.intersect(rays), oracle.intersect(sd.ptr, rays), "70-mesh intersect")
+    ds.close()
+
+
+def test_big_texture_pool_stays_in_hbm(mcrt, gpu, oracle):
+    # > 64 Ki texels: alpha predicates cannot be staged in LDS
+    g = np.random.default_rng(11)
+    px = g.uniform(0, 1, size=(300 * 300, 4)).astype(np.float32)
+    px[g.uniform(size=len(px)) < 0.3, 3] = 0.0
+    tex = abi.Texture(300, 300, px)
+    inner = scenes.build_box(scenes.solid((0.9, 0.8, 0.7, 1.0)), (0, 18, 0), (8, 8, 8))
+    outer = scenes.build_box(tex, (0, 18, 0), (8, 8, 8), 0.5)
+    sd = mcrt.SceneDesc(scenes.simple_scene([inner, outer], light=(0, 40, 30), cam_pos=(0, 18, 40), bg=(0.2, 0.3, 0.5, 1.0)))
+    cfg = abi.Config(width=80, height=60, maxBounces=2, samplesPerPixel=2)
+    scenes.assert_bit_equal(mcrt.TileRenderer.render(sd, cfg), oracle.render(sd.ptr, cfg), "big texture")
