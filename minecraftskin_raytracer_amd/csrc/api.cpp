@@ -91,6 +91,7 @@ struct mcrt_scene {
     int device = 0;
     uint32_t alpha_words = 0;
     uint32_t n_meshes = 0;
+    bool posed = false;  // any mesh with MESH_ROTATED
     DeviceBuffer blob;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
     DeviceBuffer tile_rng, scol, units, unit_hits[2], tile_mask, queues[10], targets, lit[2], stack, root_sample, counters, hit_rng;
@@ -121,6 +122,7 @@ int prepare(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layo
     p.draws_per_sample = draws_per_sample(*cfg);
     const bool fits = s->alpha_words <= static_cast<uint32_t>(kAlphaLdsWordsMax) && s->n_meshes * 6 <= static_cast<uint32_t>(kFaceLdsEntriesMax);
     p.scene_in_lds = fits ? 1 : 0;
+    p.scene_posed = s->posed ? 1 : 0;
     p.lds_alpha_words = fits ? static_cast<int>(s->alpha_words) : 0;
     p.lds_face_entries = fits ? static_cast<int>(s->n_meshes * 6) : 0;
     const WorkspaceBytes w = plan_workspace(p, target_units(), workspace_budget());
@@ -241,6 +243,11 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
     s->device = device;
     s->alpha_words = reinterpret_cast<const FlatHeader*>(b.data())->alpha_words;
     s->n_meshes = reinterpret_cast<const FlatHeader*>(b.data())->n_meshes;
+    {
+        const FlatHeader* fh = reinterpret_cast<const FlatHeader*>(b.data());
+        const FlatMesh* fm = reinterpret_cast<const FlatMesh*>(b.data() + fh->mesh_offset);
+        for (uint32_t i = 0; i < fh->n_meshes; ++i) s->posed = s->posed || (fm[i].flags & MESH_ROTATED) != 0;
+    }
     hipError_t e = s->blob.reserve(b.size());
     if (e == hipSuccess) e = hipMemcpy(s->blob.ptr, b.data(), b.size(), hipMemcpyHostToDevice);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&s->ev[i]);

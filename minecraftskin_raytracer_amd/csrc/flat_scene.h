@@ -27,7 +27,7 @@ enum : uint32_t {
 #define MCRT_TEX_NULL (-1)  /* Triangle::texture == nullptr → opaque magenta (intersection.cpp:305) */
 #define MCRT_TEX_EMPTY (-2) /* width/height <= 0 or no pixels → Color() (texture_region.h:20-22) */
 
-struct FlatMesh {  // 176 bytes
+struct FlatMesh {  // 192 bytes
     float lo[3];
     float hi[3];
     float pivot[3];
@@ -48,6 +48,11 @@ struct FlatMesh {  // 176 bytes
     // world-space bounding sphere (centre, padded radius) — a conservative pre-test for posed meshes,
     // whose exact test needs the ray in the mesh's local frame
     float sphere[4];
+    // first-pass grouping (meshes 0..63): a mesh whose box lies inside another un-posed mesh's box is
+    // that mesh's member — the first pass tests only group roots and takes the members along.
+    // group = bit i of every member incl. the root itself (0 for a non-root); see FlatHeader::root_mask
+    uint32_t group_lo, group_hi;
+    uint32_t pad[2];
 };
 
 struct FlatHeader {  // 192 bytes
@@ -73,10 +78,11 @@ struct FlatHeader {  // 192 bytes
     uint32_t alpha_offset;  // byte offset of the alpha-predicate words: 16 texels per uint32,
                             // bit 2k = (alpha == 0.0f), bit 2k+1 = (alpha > 0.0f)  (intersection.cpp:311,349)
     uint32_t alpha_words;
-    uint32_t pad2[11];
+    uint32_t root_lo, root_hi;  // bit i: mesh i (< 64) is a group root (every mesh is in exactly one group)
+    uint32_t pad2[9];
 };
 
-static_assert(sizeof(FlatMesh) == 176, "FlatMesh layout");
+static_assert(sizeof(FlatMesh) == 192, "FlatMesh layout");
 static_assert(sizeof(FlatHeader) == 192, "FlatHeader layout");
 
 #endif

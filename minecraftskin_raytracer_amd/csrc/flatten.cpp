@@ -263,6 +263,49 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
             f.screen[3] = static_cast<float>(v1);
         }
     }
+
+    // ---- first-pass groups --------------------------------------------------------------------
+    // Mesh j joins root k when both are un-posed and non-empty and box k contains box j (float
+    // compares on the stored bounds: the slab arithmetic is monotonic in the bounds, so a ray that
+    // overlaps box j overlaps box k).  One level only: a root is never a member.  Larger boxes are
+    // considered first so that nested triples attach to the outermost box.
+    {
+        const int n = d->n_meshes < 64 ? d->n_meshes : 64;
+        auto contains = [&](int k, int j) {
+            for (int a = 0; a < 3; ++a)
+                if (!(fm[k].lo[a] <= fm[j].lo[a] && fm[k].hi[a] >= fm[j].hi[a])) return false;
+            return true;
+        };
+        auto plain = [&](int i) { return (fm[i].flags & (MESH_ROTATED | MESH_EMPTY)) == 0; };
+        std::vector<int> parent(n, -1);
+        for (int j = 0; j < n; ++j) {
+            if (!plain(j)) continue;
+            for (int k = 0; k < n; ++k) {
+                if (k == j || !plain(k) || !contains(k, j)) continue;
+                if (contains(j, k) && k > j) continue;  // identical boxes: the lower index is the root
+                if (parent[j] < 0 || contains(k, parent[j])) parent[j] = k;
+            }
+        }
+        // resolve chains to the outermost ancestor (containment is transitive, so that is still valid)
+        for (int j = 0; j < n; ++j) {
+            int r = parent[j], guard = 0;
+            while (r >= 0 && parent[r] >= 0 && guard++ < 64) r = parent[r];
+            parent[j] = r;
+        }
+        uint64_t roots = 0;
+        std::vector<uint64_t> group(n, 0);
+        for (int j = 0; j < n; ++j) {
+            const int r = parent[j] < 0 ? j : parent[j];
+            group[r] |= 1ull << j;
+            if (parent[j] < 0) roots |= 1ull << j;
+        }
+        for (int j = 0; j < n; ++j) {
+            fm[j].group_lo = static_cast<uint32_t>(group[j]);
+            fm[j].group_hi = static_cast<uint32_t>(group[j] >> 32);
+        }
+        h->root_lo = static_cast<uint32_t>(roots);
+        h->root_hi = static_cast<uint32_t>(roots >> 32);
+    }
     return true;
 }
 

@@ -55,6 +55,7 @@ struct RenderParams {
     int lds_alpha_words;   // dynamic LDS: alpha-predicate words staged per workgroup
     int lds_face_entries;  // dynamic LDS: n_meshes * 6 face-table entries
     int scene_in_lds;      // 1 when both tables fit the LDS budget (otherwise the kernels read HBM)
+    int scene_posed;       // 1 when any mesh has a rotation (selects the kernels that carry the local-frame path)
     int rows_per_batch;    // owned tile rows per pipeline pass
 };
 

@@ -190,18 +190,19 @@ __device__ __forceinline__ LdsTables stage_tables(const SceneView& g, const Rend
     __syncthreads();
     return LdsTables{(const MCRT_LDS uint32_t*)s_abits, (const MCRT_LDS int*)s_faces, (const MCRT_LDS float*)s_mtab};
 }
-template <bool kLds>
-struct ViewSel;
-template <>
-struct ViewSel<true> {
-    using type = SceneViewLds;
+// kernel variants by scene: kViewHbm — tables too large for LDS (reads HBM; any pose);
+// kViewLds — tables in LDS, posed meshes present; kViewLdsUnposed — tables in LDS, no posed mesh
+constexpr int kViewHbm = 0, kViewLds = 1, kViewLdsUnposed = 2;
+template <int kView>
+struct ViewSel {
+    using type = SceneViewLdsT<kView == kViewLds>;
     static __device__ __forceinline__ type make(const SceneView& g, const RenderParams& p, unsigned char* dyn) {
         LdsTables t = stage_tables(g, p, dyn);
-        return view_with_lds(g, t.abits, t.faces, t.mtab);
+        return view_with_lds<kView == kViewLds>(g, t.abits, t.faces, t.mtab);
     }
 };
 template <>
-struct ViewSel<false> {
+struct ViewSel<kViewHbm> {
     using type = SceneView;
     static __device__ __forceinline__ type make(const SceneView& g, const RenderParams&, unsigned char*) { return g; }
 };
@@ -299,7 +300,7 @@ __device__ __forceinline__ void stream_open(TileStream& ts, uint32_t* s_mt, cons
     __syncthreads();
 }
 
-template <bool kLds>
+template <int kView>
 __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restrict__ scene_blob,
                                                          const uint32_t* __restrict__ tile_rng,
                                                          float4* __restrict__ out_frame, const RenderParams p,
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
     extern __shared__ __align__(16) unsigned char s_dyn[];
 
     const SceneView scg = view_of(scene_blob);
-    const typename ViewSel<kLds>::type sc = ViewSel<kLds>::make(scg, p, s_dyn);
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const mcrt_config& cfg = p.cfg;
     const WaveSpace& ws = p.ws;
     const int tid = threadIdx.x;
@@ -622,12 +623,12 @@ __global__ __launch_bounds__(kBlock) void light_samples_kernel(const uint8_t* __
 #ifndef MCRT_SHADE_WAVES
 #define MCRT_SHADE_WAVES 4
 #endif
-template <bool kLds>
+template <int kView>
 __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
                                                         const int level) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
-    const typename ViewSel<kLds>::type sc = ViewSel<kLds>::make(scg, p, s_dyn);
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const WaveSpace& ws = p.ws;
     const int par = level & 1;
     const int mode = shadow_mode(sc, p.cfg);
@@ -691,14 +692,14 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
 }
 
 // shade: colour of the level, reflection ray, closest hit of the next level
-template <bool kLds, bool kGeneral>
+template <int kView, bool kGeneral>
 __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
                                                        const int level) {
     __shared__ int s_wcnt[kBlock / 64];
     __shared__ uint32_t s_out_base;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
-    const typename ViewSel<kLds>::type sc = ViewSel<kLds>::make(scg, p, s_dyn);
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const mcrt_config& cfg = p.cfg;
     const WaveSpace& ws = p.ws;
     const int par = level & 1;
@@ -981,13 +982,18 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     return w;
 }
 
-template <bool kLds>
+template <int kView>
 static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn) {
     const mcrt_config& c = p.cfg;
     const bool general = needs_general_variant(c);
     const bool soft = soft_sampling(c);
     const int levels = c.max_bounces < 0 ? 0 : c.max_bounces + 1;
-    const int grid = general ? 256 : kQueueGrid;
+    static const int tuned_grid = [] {  // development knob
+        const char* e = getenv("MCRT_QUEUE_GRID");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : kQueueGrid;
+    }();
+    const int grid = general ? 256 : tuned_grid;
     for (int L = 0; L < levels; ++L) {
         if (soft && L == 0) {  // deeper levels: `shade` emits the samples of the entries it appends
             if (general)
@@ -995,11 +1001,11 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
             else
                 hipLaunchKernelGGL(light_samples_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
         }
-        hipLaunchKernelGGL(shadow_kernel<kLds>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+        hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
         if (general)
-            hipLaunchKernelGGL((shade_kernel<kLds, true>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+            hipLaunchKernelGGL((shade_kernel<kView, true>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
         else
-            hipLaunchKernelGGL((shade_kernel<kLds, false>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+            hipLaunchKernelGGL((shade_kernel<kView, false>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
     }
 }
 
@@ -1020,12 +1026,15 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t e
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(plan_units_kernel, dim3(batch_tiles), dim3(64), 0, stream, p.scene, p, tile_base, batch_tiles);
         const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
-        if (p.scene_in_lds) {
-            hipLaunchKernelGGL(primary_kernel<true>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
-            launch_levels<true>(p, stream, dyn);
+        if (p.scene_in_lds && !p.scene_posed) {
+            hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            launch_levels<kViewLdsUnposed>(p, stream, dyn);
+        } else if (p.scene_in_lds) {
+            hipLaunchKernelGGL(primary_kernel<kViewLds>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            launch_levels<kViewLds>(p, stream, dyn);
         } else {
-            hipLaunchKernelGGL(primary_kernel<false>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
-            launch_levels<false>(p, stream, 0);
+            hipLaunchKernelGGL(primary_kernel<kViewHbm>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            launch_levels<kViewHbm>(p, stream, 0);
         }
         const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
         hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, out, p);

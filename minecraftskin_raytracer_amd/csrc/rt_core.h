@@ -91,15 +91,22 @@ struct Hit {
 #define MCRT_LDS __attribute__((address_space(3)))
 struct SceneView {
     static constexpr bool kLds = false;
+    static constexpr bool kPosed = true;
     const FlatHeader* hdr;
     const FlatMesh* meshes;
     const float4* texels;
     const uint32_t* abits;
+    unsigned long long roots;  // FlatHeader::root_lo/hi
     int n_meshes;
     DEV SceneView global() const { return *this; }
 };
-struct SceneViewLds {
+// kPosedT = false: the scene holds no posed (hasRotation) mesh — selected per scene on the host; the
+// local-frame ray, the forward rotation of hit point/normal and the bounding-sphere pre-test drop
+// out of the code and of the register budget.
+template <bool kPosedT>
+struct SceneViewLdsT {
     static constexpr bool kLds = true;
+    static constexpr bool kPosed = kPosedT;
     const FlatHeader* hdr;
     const FlatMesh* meshes;
     const float4* texels;
@@ -107,9 +114,11 @@ struct SceneViewLds {
     const MCRT_LDS uint32_t* abits;  // 16 texels per word
     const MCRT_LDS int* faces;       // per (mesh, face slot): {texel offset | MCRT_TEX_*, width, height, 0}
     const MCRT_LDS float* mtab;      // per mesh kMeshTabWords words: lo hi flags . pivot . trig[8]
+    unsigned long long roots;
     int n_meshes;
-    DEV SceneView global() const { return SceneView{hdr, meshes, texels, abits_hbm, n_meshes}; }
+    DEV SceneView global() const { return SceneView{hdr, meshes, texels, abits_hbm, roots, n_meshes}; }
 };
+using SceneViewLds = SceneViewLdsT<true>;
 constexpr int kMeshTabWords = 24;
 DEV SceneView view_of(const uint8_t* blob) {
     SceneView s;
@@ -117,12 +126,14 @@ DEV SceneView view_of(const uint8_t* blob) {
     s.meshes = reinterpret_cast<const FlatMesh*>(blob + s.hdr->mesh_offset);
     s.texels = reinterpret_cast<const float4*>(blob + s.hdr->texel_offset);
     s.abits = reinterpret_cast<const uint32_t*>(blob + s.hdr->alpha_offset);
+    s.roots = (static_cast<unsigned long long>(s.hdr->root_hi) << 32) | s.hdr->root_lo;
     s.n_meshes = static_cast<int>(s.hdr->n_meshes);
     return s;
 }
-DEV SceneViewLds view_with_lds(const SceneView& g, const MCRT_LDS uint32_t* abits, const MCRT_LDS int* faces,
-                               const MCRT_LDS float* mtab) {
-    return SceneViewLds{g.hdr, g.meshes, g.texels, g.abits, abits, faces, mtab, g.n_meshes};
+template <bool kPosedT>
+DEV SceneViewLdsT<kPosedT> view_with_lds(const SceneView& g, const MCRT_LDS uint32_t* abits, const MCRT_LDS int* faces,
+                                         const MCRT_LDS float* mtab) {
+    return SceneViewLdsT<kPosedT>{g.hdr, g.meshes, g.texels, g.abits, abits, faces, mtab, g.roots, g.n_meshes};
 }
 
 DEVCALL float dev_sinf(float x) { return mcrt_sinf(x); }
@@ -387,13 +398,15 @@ struct MeshData {
     float radius;   // padded; < 0 → no bound
     uint32_t flags;
     float inv_z_cos, inv_z_sin, inv_x_cos, inv_x_sin, fwd_x_cos, fwd_x_sin, fwd_z_cos, fwd_z_sin;
+    unsigned long long group;  // first-pass group of a root (mesh_uniform only)
 };
 // wave-uniform mesh index → scalar loads from the blob
 template <class SV>
 DEV MeshData mesh_uniform(const SV& sc, int i) {
     const FlatMesh& m = sc.meshes[i];
     return MeshData{ld3(m.lo),   ld3(m.hi),   ld3(m.pivot), ld3(m.sphere), m.sphere[3], m.flags,     m.inv_z_cos,
-                    m.inv_z_sin, m.inv_x_cos, m.inv_x_sin,  m.fwd_x_cos,   m.fwd_x_sin, m.fwd_z_cos, m.fwd_z_sin};
+                    m.inv_z_sin, m.inv_x_cos, m.inv_x_sin,  m.fwd_x_cos,   m.fwd_x_sin, m.fwd_z_cos, m.fwd_z_sin,
+                    (static_cast<unsigned long long>(m.group_hi) << 32) | m.group_lo};
 }
 // per-lane mesh index → the LDS mesh table (trace kernels) or vector loads from the blob
 template <class SV>
@@ -409,6 +422,7 @@ DEV MeshData mesh_lane(const SV& sc, int i) {
         d.fwd_x_cos = t[16], d.fwd_x_sin = t[17], d.fwd_z_cos = t[18], d.fwd_z_sin = t[19];
         d.centre = mk(t[20], t[21], t[22]);
         d.radius = t[23];
+        d.group = 0ull;
         return d;
     } else {
         return mesh_uniform(sc, i);
@@ -445,9 +459,10 @@ DEV void quick_axis(bool& ok, float& tmin, float& tmax, bool par, float o, float
     tmax = smin(tmax, tf);
     if (tmin > tmax || tmax < 0.0f) ok = false;
 }
+template <bool kPosed>
 DEV bool mesh_may_hit(const MeshData& m, const RayQ& world, float t_limit) {
     if (m.flags & MESH_EMPTY) return false;
-    if (m.flags & MESH_ROTATED) {
+    if (kPosed && (m.flags & MESH_ROTATED)) {
         // posed mesh: the exact test needs the ray in the mesh's frame (phase 2).  Here only a
         // conservative bounding-sphere test — every point of the posed box lies within `radius` of
         // `centre`, so a ray that misses the padded sphere, or leaves it behind, cannot hit the box.
@@ -465,13 +480,10 @@ DEV bool mesh_may_hit(const MeshData& m, const RayQ& world, float t_limit) {
     quick_axis(ok, tmin, tmax, world.px, world.o.x, world.inv.x, m.lo.x, m.hi.x);
     quick_axis(ok, tmin, tmax, world.py, world.o.y, world.inv.y, m.lo.y, m.hi.y);
     quick_axis(ok, tmin, tmax, world.pz, world.o.z, world.inv.z, m.lo.z, m.hi.z);
-    if (!ok) return false;
-    float tHit = tmin;
-    if (tHit < 0.0f) {
-        tHit = tmax;
-        if (tHit < 0.0f) return false;
-    }
-    return tHit < t_limit;  // un-posed: local t is the reported t
+    if (!ok) return false;  // includes tmax < 0: the box lies behind the origin
+    // un-posed: local t is the reported t, so nothing of this box — or of a box inside it — can be
+    // hit before the limit unless the ray enters before the limit (origin inside: tmin < 0)
+    return tmin < t_limit;
 }
 
 // What a mesh contributes to a ray query: intersectMesh (:373-406) over intersectAABB (:200-371)
@@ -489,7 +501,7 @@ struct Cand {
 template <class SV>
 DEV bool mesh_candidate(const SV& sc, const MeshData& m, int mesh_index, const RayQ& world, float t_limit, Cand& c) {
     if (m.flags & MESH_EMPTY) return false;
-    const bool rotated = (m.flags & MESH_ROTATED) != 0;
+    const bool rotated = SV::kPosed && (m.flags & MESH_ROTATED) != 0;
     const V3 lo = m.lo, hi = m.hi;
     RayQ local = world;
     if (rotated) local = to_local(m, world);
@@ -552,18 +564,23 @@ DEV bool mesh_candidate(const SV& sc, const MeshData& m, int mesh_index, const R
     return true;
 }
 
-// Phase 1 over the scene: bit i of the result = mesh i (< 64) passed mesh_may_hit.  The loop index
-// is wave-uniform (scalar loads); meshes beyond 63 are handled by the callers' tail loops.
+// Phase 1 over the scene: bit i of the result = mesh i (< 64) may be hit.  Only group roots are
+// tested (flat_scene.h: a root's box contains its members' boxes); a passing root takes its members
+// along — phase 2 is exact, phase 1 only has to be conservative.  The loop index is wave-uniform
+// (scalar loads); meshes beyond 63 are handled by the callers' tail loops.
 template <class SV>
 DEV unsigned long long scene_candidates(const SV& sc, const RayQ& q, unsigned long long mesh_mask, float t_limit) {
     unsigned long long cand = 0ull;
     const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
+    const unsigned long long roots = sc.roots;
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
-        if (!((mesh_mask >> i) & 1ull)) continue;  // uniform: the mask is per tile
-        if (mesh_may_hit(mesh_uniform(sc, i), q, t_limit)) cand |= 1ull << i;
+        if (!((roots >> i) & 1ull)) continue;
+        const MeshData m = mesh_uniform(sc, i);
+        if (!(m.group & mesh_mask)) continue;  // uniform: the mask is per tile
+        if (mesh_may_hit<SV::kPosed>(m, q, t_limit)) cand |= m.group;
     }
-    return cand;
+    return cand & mesh_mask;
 }
 
 // intersectScene :408-421.  mesh_mask: bit i set → mesh i is tested (primary-ray culling; all
@@ -610,7 +627,7 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
         const MeshData m = mesh_lane(sc, best_mesh);
         V3 n = face_normal(best.axis, best.neg);
         if (best.back) n = n * -1.0f;  // :354
-        if (m.flags & MESH_ROTATED) {  // :400
+        if (SV::kPosed && (m.flags & MESH_ROTATED)) {  // :400
             n = normalize(spin(n, mk(0.0f, 0.0f, 0.0f), (m.flags & MESH_APPLY_X) != 0, m.fwd_x_cos, m.fwd_x_sin,
                                (m.flags & MESH_APPLY_Z) != 0, m.fwd_z_cos, m.fwd_z_sin));
         }

@@ -114,14 +114,45 @@ def test_flatten_blob_layout(mcrt):
     blob = mcrt.flatten(sd)
     hdr = np.frombuffer(blob[:16], np.uint32)
     assert hdr[0] == 0x4D435254 and hdr[1] == 12 and hdr[2] == 12 * 272  # 12 meshes, 3264 texels
-    assert len(blob) == 192 + 12 * 176 + 3264 * 16 + 3264 // 16 * 4
+    assert len(blob) == 192 + 12 * 192 + 3264 * 16 + 3264 // 16 * 4
     f = np.frombuffer(blob[:192], np.float32)
     assert np.allclose(f[12:15], [0, 18, 50]) and abs(f[15] - np.tan(np.radians(30.0))) < 1e-6  # camera pos, tan(fov/2)
     assert np.allclose(f[16:19], [0, 0, -1]) and np.allclose(f[20:23], [1, 0, 0]) and np.allclose(f[24:27], [0, 1, 0])
-    mesh0 = np.frombuffer(blob[192:192 + 176], np.float32)
+    mesh0 = np.frombuffer(blob[192:192 + 192], np.float32)
     assert np.allclose(mesh0[0:6], [-4, 24, -4, 4, 32, 4])  # head AABB (local space: the mesh is posed)
     flags = np.frombuffer(blob[192 + 68:192 + 72], np.uint32)[0]
     assert flags & 2 and flags & 4 and flags & 8 and not flags & 1  # rotated, X and Z applied, inner
+
+
+def test_flatten_first_pass_groups(mcrt):
+    """Every mesh is in exactly one group; a member's box lies inside its root's box; posed meshes are
+    their own roots (their boxes live in different frames)."""
+    for pose, expect_roots in ((0, 6), (6, None)):
+        blob = mcrt.flatten(scenes.skin_scene("S64", pose))
+        hdr = np.frombuffer(blob[:192], np.uint32)
+        n = int(hdr[1])
+        roots = int(hdr[37]) | (int(hdr[38]) << 32)
+        seen = 0
+        for i in range(n):
+            rec = blob[192 + 192 * i:192 + 192 * (i + 1)]
+            f = np.frombuffer(rec, np.float32)
+            u = np.frombuffer(rec, np.uint32)
+            group = int(u[44]) | (int(u[45]) << 32)
+            rotated = bool(u[17] & 2)
+            if not (roots >> i) & 1:
+                assert group == 0
+                continue
+            assert group & (1 << i) and not (seen & group)
+            seen |= group
+            if rotated:
+                assert group == 1 << i
+            for j in range(n):
+                if (group >> j) & 1 and j != i:
+                    g = np.frombuffer(blob[192 + 192 * j:192 + 192 * (j + 1)], np.float32)
+                    assert (f[0:3] <= g[0:3]).all() and (f[3:6] >= g[3:6]).all()
+        assert seen == (1 << n) - 1
+        if expect_roots is not None:
+            assert bin(roots).count("1") == expect_roots  # each outer-layer box encloses its inner box
 
 
 def test_flatten_rejects_malformed_scenes(mcrt):
