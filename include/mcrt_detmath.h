@@ -146,6 +146,42 @@ MCRT_HD float mcrt_sc_eval(float y, int want_cos) {
 MCRT_HD float mcrt_sinf(float y) { return mcrt_sc_eval(y, 0); }
 MCRT_HD float mcrt_cosf(float y) { return mcrt_sc_eval(y, 1); }
 
+/* sinf and cosf of the same argument with ONE argument reduction and one evaluation of each
+ * polynomial: for a given y both functions share n, the reduced x and x*x; sinf takes the sin-type
+ * polynomial when n is even and the cos-type one when n is odd, cosf the other one (mcrt_sc_eval).
+ * The results are the values mcrt_sinf(y) / mcrt_cosf(y) return, bit for bit (tools/check_detmath.cpp
+ * sweeps all 2^32 arguments).  |y| >= 120 and non-finite y take the separate functions. */
+MCRT_HD void mcrt_sincosf(float y, float* sin_out, float* cos_out) {
+    uint32_t top = (mcrt_f2u(y) >> 20) & 0x7ffu;
+    if (top >= 0x42fu) {
+        *sin_out = mcrt_sc_eval(y, 0);
+        *cos_out = mcrt_sc_eval(y, 1);
+        return;
+    }
+    {
+        double x = (double)y;
+        int n = 0;
+        double xr = x;
+        if (top >= 0x3f4u) xr = mcrt_sc_reduce_fast(x, &n);
+        {
+            int q = n & 3;
+            double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
+            double x2 = xr * xr;
+            float sp = mcrt_sc_sinpoly(xr * sgn, x2);
+            float cp = mcrt_sc_cospoly(x2, (n & 2) != 0);
+            int odd = n & 1;
+            float sv = odd ? cp : sp;
+            float cv = odd ? sp : cp;
+            if (top < 0x398u) { /* |y| < 2^-12 */
+                sv = y;
+                cv = 1.0f;
+            }
+            *sin_out = sv;
+            *cos_out = cv;
+        }
+    }
+}
+
 /* ---- powf -------------------------------------------------------------------------------- */
 MCRT_CONST_TAB double mcrt_pow_invc[16] = {
     0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010b0p+0, 0x1.3c995b0b80385p+0,

@@ -898,6 +898,11 @@ __global__ void probe_mt_kernel(const uint32_t* seeds, int n_seeds, int n_draws,
 }
 
 __device__ __forceinline__ float detmath_op(int op, float x, float y) {
+    if (op == 3 || op == 4) {  // the fused form: .s / .c
+        float sn, cs;
+        mcrt_sincosf(x, &sn, &cs);
+        return op == 3 ? sn : cs;
+    }
     return op == 0 ? mcrt_sinf(x) : (op == 1 ? mcrt_cosf(x) : mcrt_powf(x, y));
 }
 __global__ void probe_detmath_kernel(int op, const float* x, const float* y, size_t n, float* out) {

@@ -138,6 +138,15 @@ DEV SceneViewLdsT<kPosedT> view_with_lds(const SceneView& g, const MCRT_LDS uint
 
 DEVCALL float dev_sinf(float x) { return mcrt_sinf(x); }
 DEVCALL float dev_cosf(float x) { return mcrt_cosf(x); }
+struct SinCos {
+    float s, c;
+};
+// sinf and cosf of one angle: shared argument reduction, same bits as the two separate calls
+DEVCALL SinCos dev_sincosf(float x) {
+    SinCos r;
+    mcrt_sincosf(x, &r.s, &r.c);
+    return r;
+}
 DEVCALL float dev_powf(float x, float y) { return mcrt_powf(x, y); }
 
 // ---------------------------------------------------------------------------------------------
@@ -707,7 +716,9 @@ DEV V3 light_sample_on_frame(const SV& sc, const LightFrame& f, float d0, float 
     float angle = kTwoPi * d0;
     float rr = sc.hdr->light_radius * __builtin_sqrtf(d1);
     // inlined libm kernels: calls here would serialise the independent samples of a hit
-    V3 off = f.tangent * (rr * mcrt_cosf(angle)) + f.bitangent * (rr * mcrt_sinf(angle));
+    float sn, cs;
+    mcrt_sincosf(angle, &sn, &cs);
+    V3 off = f.tangent * (rr * cs) + f.bitangent * (rr * sn);
     return ld3(sc.hdr->light_pos) + off;
 }
 template <class SV>
@@ -805,7 +816,8 @@ DEV float ambient_occlusion(const SV& sc, V3 point, V3 normal, int samples, floa
         float sinT = __builtin_sqrtf(1.0f - r1);
         float cosT = __builtin_sqrtf(r1);
         float phi = kTwoPi * r2;
-        V3 local = mk(sinT * dev_cosf(phi), cosT, sinT * dev_sinf(phi));
+        const SinCos sc_phi = dev_sincosf(phi);
+        V3 local = mk(sinT * sc_phi.c, cosT, sinT * sc_phi.s);
         V3 world = normalize(T * local.x + N * local.y + B * local.z);
         Ray r{point + N * 1e-3f, world};
         if (any_hit_before(sc, r, radius)) ++occluded;
@@ -915,8 +927,9 @@ DEV Ray lens_ray(const SV& sc, float u, float v, float aspect, float aperture, f
     V3 focus = pin.o + pin.d * focusDist;
     float angle = kTwoPi * d0;
     float radius = aperture * __builtin_sqrtf(d1);
-    float lx = radius * dev_cosf(angle);
-    float ly = radius * dev_sinf(angle);
+    const SinCos sc_lens = dev_sincosf(angle);
+    float lx = radius * sc_lens.c;
+    float ly = radius * sc_lens.s;
     V3 origin = ld3(h->cam_pos) + (ld3(h->cam_right) * lx + ld3(h->cam_up) * ly);
     return Ray{origin, normalize(focus - origin)};
 }

@@ -21,6 +21,12 @@ def test_detmath_device_matches_host_on_render_domain(mcrt, gpu):
     two_pi_bits = int(np.float32(6.2831855).view(np.uint32))
     assert mcrt.probe_detmath_range(0, 0, two_pi_bits + 16) == 0  # sinf on [0, 2pi]
     assert mcrt.probe_detmath_range(1, 0, two_pi_bits + 16) == 0  # cosf on [0, 2pi]
+    # the fused sincos the kernels use for light / lens / AO samples, against the separate host functions
+    assert mcrt.probe_detmath_range(3, 0, two_pi_bits + 16) == 0
+    assert mcrt.probe_detmath_range(4, 0, two_pi_bits + 16) == 0
+    neg0 = 0x80000000
+    assert mcrt.probe_detmath_range(3, neg0, neg0 + two_pi_bits + 16) == 0  # negative arguments
+    assert mcrt.probe_detmath_range(4, neg0, neg0 + two_pi_bits + 16) == 0
     one_bits = int(np.float32(1.0).view(np.uint32))
     assert mcrt.probe_detmath_range(2, 0, one_bits + 64, 16.0) == 0  # powf(x,16) on [0, 1+]
 
