@@ -25,4 +25,4 @@ def test_detmath_matches_glibc_fma_variants(tmp_path):
                            f"{ROOT}/tools/check_detmath.cpp", "-o", str(exe), "-lpthread", "-lm"])
     out = subprocess.run([str(exe), "509"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "sin_mismatch=0 cos_mismatch=0 pow16_mismatch=0 pow_random_mismatch=0" in out.stdout
+    assert "sin_mismatch=0 cos_mismatch=0 sincos_mismatch=0 pow16_mismatch=0 pow_random_mismatch=0" in out.stdout
