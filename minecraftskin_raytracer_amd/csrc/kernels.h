@@ -17,6 +17,10 @@ struct Shard {
     int tiles_x;     // tile columns
     int tiles_y;     // tile rows in the whole frame
     int owned_rows;  // number of tile rows owned
+    // MCRT_LAYOUT_PACKED: owned row j is stored as packed tile row pack_first + j * pack_step (a lane
+    // of a rank's shard writes into the rank's packed buffer; plain shards use 0 / 1)
+    int pack_first;
+    int pack_step;
 };
 
 // Device workspace of the wavefront pipeline (all HBM; sized for one batch of tile rows in which

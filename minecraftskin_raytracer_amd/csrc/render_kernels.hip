@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                         ab += c.b;
                         aa += c.a;
                     }
-                    const int row = (p.layout == MCRT_LAYOUT_PACKED) ? (tg.owned_row * cfg.tile_size + ly) : (tg.y + ly);
+                    const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
                     out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
                         make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp);
                 }
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                     const unsigned uly = pix / static_cast<unsigned>(tg.w);
                     const int ly = static_cast<int>(uly);
                     const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
-                    const int row = (p.layout == MCRT_LAYOUT_PACKED) ? (tg.owned_row * cfg.tile_size + ly) : (tg.y + ly);
+                    const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
                     out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
                         make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
                 } else {
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(float4* __restrict__ ou
             const uint32_t uly = i / static_cast<uint32_t>(tg.w);
             const int ly = static_cast<int>(uly);
             const int lx = static_cast<int>(i - uly * static_cast<uint32_t>(tg.w));
-            const int row = (p.layout == MCRT_LAYOUT_PACKED) ? (tg.owned_row * cfg.tile_size + ly) : (tg.y + ly);
+            const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
             out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
                 make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
         }
@@ -923,6 +923,8 @@ Shard make_shard(const mcrt_config& cfg, int first, int step) {
     Shard s{};
     s.first = first;
     s.step = step < 1 ? 1 : step;
+    s.pack_first = 0;
+    s.pack_step = 1;
     if (cfg.width <= 0 || cfg.height <= 0 || cfg.tile_size <= 0) return s;
     s.tiles_x = (cfg.width + cfg.tile_size - 1) / cfg.tile_size;
     s.tiles_y = (cfg.height + cfg.tile_size - 1) / cfg.tile_size;

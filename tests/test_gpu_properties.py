@@ -176,3 +176,54 @@ def test_multi_batch_render_matches_single_batch(mcrt, gpu, tmp_path):
     sd = scenes.skin_scene("S64", 6)  # keep the description alive while the oracle reads it
     ref = oraclelib.Oracle().render(sd.ptr, cfg)
     scenes.assert_bit_equal(a, ref, "multi-batch render vs oracle")
+
+
+def test_lanes_render_the_same_frame(mcrt, gpu, tmp_path):
+    """A render is split over 1..4 lanes (streams with their own workspace, every n-th tile row of the
+    shard each); whole frames and packed rank shards must come out bit-identical for any lane
+    count, also combined with a tiny budget.  (MCRT_LANES is read once per process → subprocess.)"""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "render_lanes.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.abspath(__file__)))})\n"
+        "import minecraftskin_raytracer_amd as M, scenes\n"
+        "from minecraftskin_raytracer_amd import abi\n"
+        "cfg = M.Config(width=333, height=250, maxBounces=3, samplesPerPixel=4, tileSize=16)\n"
+        "ds = M.DeviceScene(scenes.skin_scene('S64', 6))\n"
+        "st = torch.cuda.current_stream().cuda_stream\n"
+        "frame = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.float32, device='cuda')\n"
+        "ds.render_device(cfg, frame.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st)\n"
+        "rows = ds.owned_pixel_rows(cfg, 1, 3)\n"
+        "packed = torch.zeros((rows, cfg.width, 4), dtype=torch.float32, device='cuda')\n"
+        "ds.render_device(cfg, packed.data_ptr(), 1, 3, abi.LAYOUT_PACKED, st)\n"
+        "shard = torch.zeros_like(frame)\n"
+        "M.unpack_rows_device(cfg, 1, 3, packed.data_ptr(), shard.data_ptr(), st)\n"
+        "torch.cuda.synchronize()\n"
+        "np.savez(sys.argv[1], frame=frame.cpu().numpy(), shard=shard.cpu().numpy())\n")
+    outs = {}
+    for lanes, budget in (("1", None), ("2", None), ("3", None), ("4", None), ("3", "8")):
+        env = dict(os.environ, MCRT_LANES=lanes)
+        if budget:
+            env["MCRT_WORKSPACE_MB"] = budget
+        path = str(tmp_path / f"lanes{lanes}_{budget}.npz")
+        subprocess.check_call([sys.executable, str(script), path], env=env)
+        outs[(lanes, budget)] = np.load(path)
+    base = outs[("1", None)]
+    T, H = 16, 250
+    owned = np.zeros(H, bool)
+    for r in range(1, (H + T - 1) // T, 3):
+        owned[r * T:min(H, (r + 1) * T)] = True
+    assert np.array_equal(base["shard"][owned].view(np.uint32), base["frame"][owned].view(np.uint32))
+    assert not base["shard"][~owned].any()
+    for key, o in outs.items():
+        assert np.array_equal(o["frame"].view(np.uint32), base["frame"].view(np.uint32)), key
+        assert np.array_equal(o["shard"].view(np.uint32), base["shard"].view(np.uint32)), key
+    import oraclelib
+    cfg = abi.Config(width=333, height=250, maxBounces=3, samplesPerPixel=4, tileSize=16)
+    sd = scenes.skin_scene("S64", 6)
+    scenes.assert_bit_equal(base["frame"], oraclelib.Oracle().render(sd.ptr, cfg), "lanes render vs oracle")
