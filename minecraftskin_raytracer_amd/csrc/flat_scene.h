@@ -52,7 +52,10 @@ struct FlatMesh {  // 192 bytes
     // that mesh's member — the first pass tests only group roots and takes the members along.
     // group = bit i of every member incl. the root itself (0 for a non-root); see FlatHeader::root_mask
     uint32_t group_lo, group_hi;
-    uint32_t pad[2];
+    // camera-space depth range (along the camera's forward axis) of the box corners, valid when the
+    // screen bound is: thin-lens rays shift a point's image by lens_offset * (1/z - 1/z_focus), so the
+    // bound is dilated by that much when depth of field is on
+    float depth[2];
 };
 
 struct FlatHeader {  // 192 bytes

@@ -230,7 +230,7 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
         // must never be too small; any doubt → "never cull" (u0 > u1).
         f.screen[0] = 1.0f, f.screen[1] = 1.0f, f.screen[2] = 0.0f, f.screen[3] = 0.0f;
         bool bound_ok = cull_ok && ntri > 0;
-        double u0 = 1e30, v0 = 1e30, u1 = -1e30, v1 = -1e30;
+        double u0 = 1e30, v0 = 1e30, u1 = -1e30, v1 = -1e30, z0 = 1e30, z1 = -1e30;
         for (int c = 0; c < 8 && bound_ok; ++c) {
             double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
             double w[3];
@@ -253,6 +253,7 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
             double nu = su / half_h, nv = sv / half_h;
             u0 = std::fmin(u0, nu), u1 = std::fmax(u1, nu);
             v0 = std::fmin(v0, nv), v1 = std::fmax(v1, nv);
+            z0 = std::fmin(z0, zc), z1 = std::fmax(z1, zc);
         }
         if (bound_ok && std::isfinite(u0 + u1 + v0 + v1)) {
             // stored in "halfH units": x range [u0,u1] (divide by aspect to get [-1,1]), y range
@@ -261,6 +262,8 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
             f.screen[1] = static_cast<float>(v0);
             f.screen[2] = static_cast<float>(u1);
             f.screen[3] = static_cast<float>(v1);
+            f.depth[0] = static_cast<float>(z0 * 0.99);  // z0 > 0: every corner is in front of the camera
+            f.depth[1] = static_cast<float>(z1 * 1.01);
         }
     }
 

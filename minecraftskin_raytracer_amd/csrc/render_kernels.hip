@@ -136,10 +136,13 @@ __device__ __forceinline__ void stream_fill(TileStream& ts, float* jit, int blk,
 // ---------------------------------------------------------------------------------------------
 // primary-ray culling mask of a tile
 // ---------------------------------------------------------------------------------------------
+// lens_pad: how far a thin-lens ray can displace the image of a point of this mesh, in the bound's
+// units (0 for the pinhole camera)
 __device__ __forceinline__ bool mesh_touches_tile(const FlatMesh& m, const TileGeom& t, const mcrt_config& cfg,
-                                                  float aspect) {
-    const float u0 = m.screen[0], v0 = m.screen[1], u1 = m.screen[2], v1 = m.screen[3];
+                                                  float aspect, float lens_pad) {
+    float u0 = m.screen[0], v0 = m.screen[1], u1 = m.screen[2], v1 = m.screen[3];
     if (u0 > u1) return true;  // no bound available
+    u0 -= lens_pad, v0 -= lens_pad, u1 += lens_pad, v1 += lens_pad;
     const float W = static_cast<float>(cfg.width), H = static_cast<float>(cfg.height);
     // tile extent padded by 2 pixels, in the bound's units (x: (2u-1)*aspect, y: 1-2v, +y up)
     float tu0 = (2.0f * (static_cast<float>(t.x) - 2.0f) / W - 1.0f) * aspect - 1e-3f * aspect - 1e-3f;
@@ -255,10 +258,30 @@ __global__ __launch_bounds__(64) void plan_units_kernel(const uint8_t* __restric
     const TileGeom tg = tile_of(p, tile);
     const int lane = threadIdx.x;
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
-    const bool cull = sc.hdr->cull_ok != 0 && !dof && sc.n_meshes < 64;
+    const bool cull = sc.hdr->cull_ok != 0 && sc.n_meshes < 64;
     const float aspect = static_cast<float>(cfg.width) / static_cast<float>(cfg.height);
     bool touch = lane < sc.n_meshes;
-    if (touch && cull) touch = mesh_touches_tile(sc.meshes[lane], tg, cfg, aspect);
+    if (touch && cull) {
+        const FlatMesh& m = sc.meshes[lane];
+        float lens_pad = 0.0f;
+        if (dof) {
+            // Thin lens (tile_renderer.cpp:42-69): the ray of screen sample s leaves the lens at offset
+            // (lx, ly), |.| <= aperture, towards the focus point of the pinhole ray, so a point at
+            // camera depth z on it is seen by the pinhole at s + (lx, ly) * (1/z - 1/zf), where
+            // zf = focusDist / |(su, sv, 1)| is the depth of that focus point.  Over the mesh's depth
+            // range and every zf of the frame this bounds the displacement; generous float slack.
+            const float half_h = sc.hdr->cam_half_h, half_w = half_h * aspect;
+            const float focus = cfg.focus_distance > 0.0f ? cfg.focus_distance : sc.hdr->cam_focus_auto;
+            const float inv_f_lo = 1.0f / focus;
+            const float inv_f_hi = __builtin_sqrtf(1.0f + half_w * half_w + half_h * half_h) / focus;
+            const float inv_z_hi = 1.0f / m.depth[0], inv_z_lo = 1.0f / m.depth[1];
+            const float d = fmaxf(fmaxf(fabsf(inv_z_hi - inv_f_lo), fabsf(inv_z_hi - inv_f_hi)),
+                                  fmaxf(fabsf(inv_z_lo - inv_f_lo), fabsf(inv_z_lo - inv_f_hi)));
+            lens_pad = cfg.aperture * d / half_h * 1.02f + 1e-3f;
+            if (!(m.depth[0] > 0.0f) || !(focus > 0.0f) || !(lens_pad < 1e6f)) lens_pad = 1e30f;  // no bound
+        }
+        touch = mesh_touches_tile(m, tg, cfg, aspect, lens_pad);
+    }
     unsigned long long mask = __ballot(touch);
     if (!cull && sc.n_meshes > 0) mask = ~0ull;
     if (lane != 0) return;
@@ -691,6 +714,85 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
     });
 }
 
+// ambient occlusion (raytracer.cpp:38-78, depth 0 only) as two stages after the level-0 shadows:
+// ao_dirs — lane per hit: tangent frame, mt19937(ao seed), the A cosine-weighted directions, stored
+// where the (now consumed) light samples of level 0 were; ao — lane per (hit, direction): any hit
+// closer than the radius, counted per hit into lit[1] (free until the level-1 shadows).
+__global__ __launch_bounds__(kBlock) void ao_dirs_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    const WaveSpace& ws = p.ws;
+    const int A = p.cfg.ao_samples;
+    (void)scene_blob;
+    for_each_entry_block(ws, 0, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+        if (threadIdx.x >= n) return;
+        const uint32_t e = first + threadIdx.x;
+        const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
+        const V3 P = mk(hp.x, hp.y, hp.z);
+        const V3 N = normalize(mk(hn.x, hn.y, hn.z));
+        const V3 T = (__builtin_fabsf(N.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), N)) : normalize(cross(mk(0, 1, 0), N));
+        const V3 B = cross(N, T);
+        MtShort rng;
+        rng.seed(ao_seed(P));
+        float* dst = ws.targets + static_cast<size_t>(e) * 3 * A;
+        for (int i = 0; i < A; ++i) {
+            const float r1 = rng.uniform();
+            const float r2 = rng.uniform();
+            const float sinT = __builtin_sqrtf(1.0f - r1);
+            const float cosT = __builtin_sqrtf(r1);
+            float sn, cs;
+            mcrt_sincosf(kTwoPi * r2, &sn, &cs);
+            const V3 local = mk(sinT * cs, cosT, sinT * sn);
+            const V3 world = normalize(T * local.x + N * local.y + B * local.z);
+            dst[3 * i + 0] = world.x;
+            dst[3 * i + 1] = world.y;
+            dst[3 * i + 2] = world.z;
+        }
+    });
+}
+
+template <int kView>
+__global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const SceneView scg = view_of(scene_blob);
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
+    const WaveSpace& ws = p.ws;
+    const uint32_t A = static_cast<uint32_t>(p.cfg.ao_samples);
+    const float radius = p.cfg.ao_radius;
+    const bool pow2 = (A & (A - 1u)) == 0u && A <= 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* occ_out = ws.lit[1];
+    for_each_entry_block(ws, 0, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+        if (!pow2) {
+            if (threadIdx.x < n) occ_out[first + threadIdx.x] = 0u;
+            __syncthreads();
+        }
+        const uint32_t total = n * A;
+        for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) {  // uniform trip count per wave
+            const uint32_t q = q0 + lane;
+            bool occluded = false;
+            uint32_t e = 0;
+            if (q < total) {
+                const uint32_t k = q / A;
+                const uint32_t j = q - k * A;
+                e = first + k;
+                const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
+                const V3 N = normalize(mk(hn.x, hn.y, hn.z));
+                const V3 dir = ld3(ws.targets + (static_cast<size_t>(e) * A + j) * 3);
+                const Ray r{mk(hp.x, hp.y, hp.z) + N * 1e-3f, dir};
+                occluded = any_hit_inline(sc, r, radius);
+            }
+            if (pow2) {
+                const unsigned long long m = __ballot(occluded);
+                if (q < total && (lane & (A - 1u)) == 0u) {
+                    const unsigned long long grp = (A == 64u) ? m : ((m >> lane) & ((1ull << A) - 1ull));
+                    occ_out[e] = static_cast<uint32_t>(__popcll(grp));
+                }
+            } else if (occluded) {
+                atomicAdd(&occ_out[e], 1u);
+            }
+        }
+    });
+}
+
 // shade: colour of the level, reflection ray, closest hit of the next level
 template <int kView, bool kGeneral>
 __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
@@ -738,8 +840,16 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
             C4 c;
             if constexpr (kGeneral)
                 c = level_color(sc, cfg, ray.o, hit, depth, vis, my_rng);
-            else
+            else {
                 c = shade(sc, hit, normalize(ray.o - hit.p), vis);
+                if (cfg.ao_enabled && level == 0) {  // raytracer.cpp:121-130; occluded count from the ao stage
+                    const float ao = 1.0f - static_cast<float>(ws.lit[1][e]) / static_cast<float>(cfg.ao_samples);
+                    const float k = 1.0f - cfg.ao_intensity * (1.0f - ao);
+                    c.r *= k;
+                    c.g *= k;
+                    c.b *= k;
+                }
+            }
             bool done = false;
             C4 tail = flat_bg;
             int pushed = depth;
@@ -935,9 +1045,10 @@ Shard make_shard(const mcrt_config& cfg, int first, int step) {
 static int owned_tiles(const RenderParams& p) { return p.shard.owned_rows * p.shard.tiles_x; }
 static bool soft_sampling(const mcrt_config& c) { return c.soft_shadows && c.shadow_samples > 1; }
 
-// rare features that need the general kernel variants (long per-hit RNG streams, AO)
+// rare feature that needs the general kernel variants: per-hit RNG streams longer than the
+// register-only engine covers (they run AO inside `shade`, sequentially)
 static bool needs_general_variant(const mcrt_config& c) {
-    return c.ao_enabled || (soft_sampling(c) && 2 * c.shadow_samples > kMtShortMax);
+    return (c.ao_enabled && (c.ao_samples <= 0 || 2 * c.ao_samples > kMtShortMax)) || (soft_sampling(c) && 2 * c.shadow_samples > kMtShortMax);
 }
 
 // Parts of a tile that meshes can touch: one 256-sample chunk each, at most 16 — fine enough that
@@ -965,7 +1076,9 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     const size_t row_samples = static_cast<size_t>(c.tile_size) * c.tile_size * static_cast<size_t>(p.shard.tiles_x) * spp;
     const size_t S = soft_sampling(c) ? static_cast<size_t>(c.shadow_samples) : 0;
     // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
-    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * S + 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
+    const size_t A = c.ao_enabled && c.ao_samples > 0 ? static_cast<size_t>(c.ao_samples) : 0;
+    const size_t rays = S > A ? S : A;  // light samples and AO directions share one array
+    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
     size_t rows = budget_bytes / (per_entry * (row_samples ? row_samples : 1));
     if (rows < 1) rows = 1;
     if (rows > static_cast<size_t>(p.shard.owned_rows)) rows = p.shard.owned_rows > 0 ? p.shard.owned_rows : 1;
@@ -979,13 +1092,12 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     w.unit_hits = static_cast<size_t>(p.ws.unit_cap) * 4;
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
     w.queue_each = cap * 16;
-    w.targets = cap * 12 * S;
+    w.targets = cap * 12 * rays;
     w.lit = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
     w.root_sample = cap * 4;
     w.counters = static_cast<size_t>(kCounterWords) * 4;
-    const bool long_rng = (soft_sampling(c) && 2 * c.shadow_samples > kMtShortMax) || (c.ao_enabled && 2 * c.ao_samples > kMtShortMax);
-    w.hit_rng = long_rng ? static_cast<size_t>(256) * kBlock * 624 * 4 : 0;  // general grids are capped at 256 WGs
+    w.hit_rng = needs_general_variant(c) ? static_cast<size_t>(256) * kBlock * 624 * 4 : 0;  // general grids are capped at 256 WGs
     return w;
 }
 
@@ -1009,6 +1121,10 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
                 hipLaunchKernelGGL(light_samples_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
         }
         hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+        if (L == 0 && c.ao_enabled && c.ao_samples > 0 && !general) {
+            hipLaunchKernelGGL(ao_dirs_kernel, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
+            hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
+        }
         if (general)
             hipLaunchKernelGGL((shade_kernel<kView, true>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
         else

@@ -152,6 +152,21 @@ VARIANT_CASES = [
     ("S32", 1, dict(width=24, height=20, maxBounces=1, samplesPerPixel=2, tileSize=1)),
     # DOF with many samples (4 draws per sample), large spp → sample-per-thread background path
     ("S64", 0, dict(width=40, height=24, maxBounces=1, samplesPerPixel=40, dofEnabled=True, aperture=0.8, focusDistance=45.0)),
+    # ambient occlusion as its own stage (ballot counts for power-of-two sample counts, atomics otherwise),
+    # with and without soft shadows, more AO directions than light samples and fewer
+    ("S64", 0, dict(width=96, height=64, maxBounces=2, samplesPerPixel=2, aoEnabled=True, aoSamples=16)),
+    ("S64", 6, dict(width=80, height=60, maxBounces=1, samplesPerPixel=1, aoEnabled=True, aoSamples=5, aoRadius=6.0, aoIntensity=0.9)),
+    ("S64", 3, dict(width=64, height=48, maxBounces=3, samplesPerPixel=2, aoEnabled=True, aoSamples=4, shadowSamples=16)),
+    ("S32", 0, dict(width=64, height=48, maxBounces=1, samplesPerPixel=1, aoEnabled=True, aoSamples=64, softShadows=False)),
+    ("S64", 0, dict(width=48, height=32, maxBounces=0, samplesPerPixel=3, aoEnabled=True, aoSamples=1)),
+    # the reference GUI's default feature set (AO 16 + DOF), small
+    ("S64", 0, dict(width=120, height=68, maxBounces=4, samplesPerPixel=8, aoEnabled=True, aoSamples=16, dofEnabled=True, aperture=0.3)),
+    # DOF with tile culling: small tiles, blur circles from a few pixels to wider than the character
+    # (focus in front of / on / far behind the figure, auto focus), posed and un-posed
+    ("S64", 0, dict(width=240, height=160, maxBounces=1, samplesPerPixel=2, tileSize=8, dofEnabled=True, aperture=0.3)),
+    ("S64", 6, dict(width=240, height=160, maxBounces=1, samplesPerPixel=2, tileSize=8, dofEnabled=True, aperture=2.5, focusDistance=20.0)),
+    ("S64", 3, dict(width=200, height=120, maxBounces=0, samplesPerPixel=3, tileSize=5, dofEnabled=True, aperture=1.2, focusDistance=400.0)),
+    ("S32", 0, dict(width=160, height=200, maxBounces=1, samplesPerPixel=2, tileSize=16, dofEnabled=True, aperture=6.0, focusDistance=50.0)),
 ]
 
 
