@@ -154,6 +154,13 @@ void mcrt_scene_destroy(mcrt_scene* scene);
 int mcrt_render_device(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_first,
                        int tile_row_step, int out_layout, float* d_out_rgba, void* stream);
 
+/* Same render with the quantisation fused into the epilogue: writes the float4 frame to d_out_f32
+ * and/or `(uint8_t)(clamp(c,0,1)*255.0f+0.5f)` per channel to d_out_rgba8 (either may be NULL, not
+ * both) — the RGBA8 plane is what ImageWriter::writePNG hands to the PNG encoder
+ * (/root/reference/src/output/image_writer.cpp:16-26), 4 B/pixel to copy back instead of 16. */
+int mcrt_render_device_ex(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_first, int tile_row_step,
+                          int layout, float* d_out_f32, uint8_t* d_out_rgba8, void* stream);
+
 /* number of pixel rows owned by (first, step) and therefore the packed buffer height */
 int mcrt_owned_pixel_rows(const mcrt_config* cfg, int tile_row_first, int tile_row_step);
 
@@ -166,6 +173,21 @@ int mcrt_unpack_rows_device(const mcrt_config* cfg, int tile_row_first, int tile
  * (/root/reference/src/output/image_writer.cpp:18-22 ≡ src/skin/image.cpp:31-36). */
 int mcrt_quantize_rgba8_device(const float* d_rgba, uint8_t* d_out, size_t n_pixels, void* stream);
 void mcrt_quantize_rgba8(const float* rgba, uint8_t* out, size_t n_pixels);
+
+/* ---- PNG hand-off (the step after the path: ImageWriter::writePNG, image_writer.cpp:6-28) -------- */
+/* Writes an 8-bit RGBA PNG (colour type 6, no interlace, filter 0, zlib *stored* blocks: no
+ * compression, bounded by memory bandwidth).  Any PNG reader decodes it to the same pixels the
+ * reference's stbi_write_png output decodes to.  Returns MCRT_OK or MCRT_ERR_INVALID (bad
+ * arguments, or the file cannot be created / written — writePNG's `false`). */
+int mcrt_write_png_rgba8(const char* path, const uint8_t* rgba, int width, int height);
+/* In-memory form: returns the PNG size; writes it when `capacity` suffices. */
+size_t mcrt_encode_png_rgba8(const uint8_t* rgba, int width, int height, uint8_t* out, size_t capacity);
+/* Quantise a float RGBA image exactly like ImageWriter::writePNG and write it. */
+int mcrt_write_png_f32(const char* path, const float* rgba, int width, int height);
+/* TileRenderer::render + ImageWriter::writePNG in one call: render on `device`, quantise in the
+ * kernel epilogue, copy 4 B/pixel back, write the file.  Invalid frame sizes write nothing and
+ * return MCRT_ERR_INVALID (writePNG rejects empty images, image_writer.cpp:7-9). */
+int mcrt_render_png(const mcrt_scene_desc* scene, const mcrt_config* cfg, const char* path, int device);
 
 /* timings of the last mcrt_render() on this thread, milliseconds */
 typedef struct mcrt_timings {

@@ -3,6 +3,7 @@ from .abi import Config, Mesh, Scene, Texture  # noqa: F401
 from .skins import synthetic_skin  # noqa: F401
 from .api import (  # noqa: F401
     DeviceScene,
+    ImageWriter,
     MeshBuilder,
     SceneDesc,
     TileRenderer,
@@ -14,11 +15,12 @@ from .api import (  # noqa: F401
     probe_mt_uniform,
     quantize_rgba8,
     quantize_rgba8_device,
+    render_png,
     unpack_rows_device,
 )
 
 __all__ = [
     "Config", "Mesh", "Scene", "Texture", "synthetic_skin", "DeviceScene", "MeshBuilder", "SceneDesc",
     "TileRenderer", "device_count", "flatten", "getBuiltinPoses", "probe_detmath", "probe_detmath_range",
-    "probe_mt_uniform", "quantize_rgba8", "quantize_rgba8_device", "unpack_rows_device",
+    "probe_mt_uniform", "quantize_rgba8", "quantize_rgba8_device", "unpack_rows_device", "ImageWriter", "render_png",
 ]

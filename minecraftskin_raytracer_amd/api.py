@@ -7,6 +7,7 @@ behaviour too; every render goes through the C ABI of ``libmcrt.so`` into the HI
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -149,6 +150,44 @@ def quantize_rgba8(image: np.ndarray) -> np.ndarray:
     return out
 
 
+class ImageWriter:
+    """The reference's PNG hand-off (src/output/image_writer.h): quantise + write.  The file is an
+    uncompressed (zlib-stored) 8-bit RGBA PNG written by the library's own store-only encoder."""
+
+    @staticmethod
+    def writePNG(image: np.ndarray, path: str) -> bool:
+        """(H, W, 4) float32 → PNG at `path`.  False on failure (empty image, unwritable path), like
+        ImageWriter::writePNG (image_writer.cpp:6-28)."""
+        img = np.ascontiguousarray(image, np.float32)
+        if img.ndim != 3 or img.shape[2] != 4 or img.shape[0] <= 0 or img.shape[1] <= 0:
+            return False
+        return load().mcrt_write_png_f32(os.fsencode(path), abi.fptr(img), img.shape[1], img.shape[0]) == 0
+
+    @staticmethod
+    def writePNG8(rgba8: np.ndarray, path: str) -> bool:
+        img = np.ascontiguousarray(rgba8, np.uint8)
+        if img.ndim != 3 or img.shape[2] != 4 or img.shape[0] <= 0 or img.shape[1] <= 0:
+            return False
+        return load().mcrt_write_png_rgba8(os.fsencode(path), img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[0]) == 0
+
+    @staticmethod
+    def encodePNG8(rgba8: np.ndarray) -> bytes:
+        img = np.ascontiguousarray(rgba8, np.uint8)
+        h, w = img.shape[:2]
+        p = img.ctypes.data_as(C.POINTER(C.c_uint8))
+        n = load().mcrt_encode_png_rgba8(p, w, h, None, 0)
+        buf = (C.c_uint8 * n)()
+        got = load().mcrt_encode_png_rgba8(p, w, h, buf, n)
+        return bytes(buf[:got])
+
+
+def render_png(scene, config: Config, path: str, device: int = 0) -> bool:
+    """TileRenderer::render + ImageWriter::writePNG in one call (RGBA8 quantised in the kernel epilogue,
+    4 B/pixel copied back)."""
+    c = config.to_c()
+    return load().mcrt_render_png(_as_desc(scene).ptr, C.byref(c), os.fsencode(path), device) == 0
+
+
 class DeviceScene:
     """A flattened scene resident in HBM on one device (mcrt_scene).  Renders go to device pointers
     (e.g. ``torch.Tensor.data_ptr()``) on a caller-chosen HIP stream."""
@@ -178,6 +217,13 @@ class DeviceScene:
                       layout: int = abi.LAYOUT_FRAME, stream: int = 0) -> None:
         c = config.to_c()
         check(load().mcrt_render_device(self._h, C.byref(c), first, step, layout, C.c_void_p(out_ptr), C.c_void_p(stream)))
+
+    def render_device_ex(self, config: Config, out_f32_ptr: int = 0, out_rgba8_ptr: int = 0, first: int = 0, step: int = 1,
+                         layout: int = abi.LAYOUT_FRAME, stream: int = 0) -> None:
+        """Render with the quantisation fused into the epilogue: float4 frame and/or RGBA8 plane."""
+        c = config.to_c()
+        check(load().mcrt_render_device_ex(self._h, C.byref(c), first, step, layout, C.c_void_p(out_f32_ptr or None),
+                                           C.c_void_p(out_rgba8_ptr or None), C.c_void_p(stream)))
 
     def time_render_device(self, config: Config, out_ptr: int, iters: int, first: int = 0, step: int = 1,
                            layout: int = abi.LAYOUT_FRAME, stream: int = 0) -> Tuple[float, float]:

@@ -207,4 +207,9 @@ private:
     static std::vector<TileError> errors_;
 };
 
+class ImageWriter {  // output/image_writer.h:6-12
+public:
+    static bool writePNG(const Image& image, const std::string& path);
+};
+
 #endif

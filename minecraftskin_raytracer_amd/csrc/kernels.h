@@ -51,7 +51,8 @@ struct RenderParams {
     mcrt_config cfg;
     Shard shard;
     int layout;            // MCRT_LAYOUT_*
-    float* out;            // float4 frame or packed rows
+    float* out;            // float4 frame or packed rows (may be NULL when out8 is given)
+    uint8_t* out8;         // RGBA8 frame or packed rows, quantised in the epilogue (may be NULL)
     uint32_t* tile_rng;    // owned_tiles x 624 seeded mt19937 words (NULL when no tile draws)
     WaveSpace ws;
     int draws_per_sample;  // 0, 2 or 4

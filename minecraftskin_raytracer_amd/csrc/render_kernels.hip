@@ -134,6 +134,23 @@ __device__ __forceinline__ void stream_fill(TileStream& ts, float* jit, int blk,
     __syncthreads();
 }
 // ---------------------------------------------------------------------------------------------
+// pixel store: the float4 frame and/or its RGBA8 quantisation `(u8)(clamp(c,0,1)*255+0.5)`
+// (image_writer.cpp:18-22 ≡ image.cpp:31-36) — the epilogue of `primary` (background tiles) and `resolve`
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uchar4 quantize_pixel(float4 c) {
+    uchar4 q;
+    q.x = static_cast<unsigned char>(sclamp(c.x, 0.0f, 1.0f) * 255.0f + 0.5f);
+    q.y = static_cast<unsigned char>(sclamp(c.y, 0.0f, 1.0f) * 255.0f + 0.5f);
+    q.z = static_cast<unsigned char>(sclamp(c.z, 0.0f, 1.0f) * 255.0f + 0.5f);
+    q.w = static_cast<unsigned char>(sclamp(c.w, 0.0f, 1.0f) * 255.0f + 0.5f);
+    return q;
+}
+__device__ __forceinline__ void store_pixel(float4* __restrict__ out_frame, uchar4* __restrict__ out8, size_t idx, float4 v) {
+    if (out_frame) out_frame[idx] = v;
+    if (out8) out8[idx] = quantize_pixel(v);
+}
+
+// ---------------------------------------------------------------------------------------------
 // primary-ray culling mask of a tile
 // ---------------------------------------------------------------------------------------------
 // lens_pad: how far a thin-lens ray can displace the image of a point of this mesh, in the bound's
@@ -326,7 +343,7 @@ __device__ __forceinline__ void stream_open(TileStream& ts, uint32_t* s_mt, cons
 template <int kView>
 __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restrict__ scene_blob,
                                                          const uint32_t* __restrict__ tile_rng,
-                                                         float4* __restrict__ out_frame, const RenderParams p,
+                                                         float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p,
                                                          const int tile_base, const int n_tiles) {
     __shared__ uint32_t s_mt[2 * 624];
     __shared__ float s_jit[kJitFloats];
@@ -473,8 +490,8 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                         aa += c.a;
                     }
                     const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
-                    out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
-                        make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp);
+                    store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
+                                make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp));
                 }
                 if (dd > 0) __syncthreads();  // s_jit is refilled by the next pass
             }
@@ -532,8 +549,8 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                     const int ly = static_cast<int>(uly);
                     const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
                     const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
-                    out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
-                        make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
+                    store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
+                                make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp));
                 } else {
                     s_carry[parity] = acc;
                 }
@@ -898,7 +915,7 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
 }
 
 // resolve: ordered per-pixel sum of the queued units' sample colours (tile_renderer.cpp:116-124)
-__global__ __launch_bounds__(kBlock) void resolve_kernel(float4* __restrict__ out_frame, const RenderParams p) {
+__global__ __launch_bounds__(kBlock) void resolve_kernel(float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p) {
     const WaveSpace& ws = p.ws;
     const mcrt_config& cfg = p.cfg;
     const uint32_t n_units = ws.counters[kCntUnits];
@@ -922,8 +939,8 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(float4* __restrict__ ou
             const int ly = static_cast<int>(uly);
             const int lx = static_cast<int>(i - uly * static_cast<uint32_t>(tg.w));
             const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
-            out_frame[static_cast<size_t>(row) * cfg.width + (tg.x + lx)] =
-                make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp);
+            store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
+                        make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp));
         }
     }
 }
@@ -948,13 +965,7 @@ __global__ void unpack_rows_kernel(mcrt_config cfg, Shard sh, const float4* pack
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, size_t n) {  // image_writer.cpp:18-22
     size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 c = rgba[i];
-    uchar4 q;
-    q.x = static_cast<unsigned char>(sclamp(c.x, 0.0f, 1.0f) * 255.0f + 0.5f);
-    q.y = static_cast<unsigned char>(sclamp(c.y, 0.0f, 1.0f) * 255.0f + 0.5f);
-    q.z = static_cast<unsigned char>(sclamp(c.z, 0.0f, 1.0f) * 255.0f + 0.5f);
-    q.w = static_cast<unsigned char>(sclamp(c.w, 0.0f, 1.0f) * 255.0f + 0.5f);
-    out[i] = q;
+    out[i] = quantize_pixel(rgba[i]);
 }
 
 __global__ void probe_intersect_kernel(const uint8_t* scene, const float* rays, int n, mcrt_hit* out) {
@@ -1141,6 +1152,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t e
                                             static_cast<size_t>(p.lds_alpha_words) * 4
                                       : 0;
     float4* out = reinterpret_cast<float4*>(p.out);
+    uchar4* out8 = reinterpret_cast<uchar4*>(p.out8);
     for (int r0 = 0; r0 < p.shard.owned_rows; r0 += p.rows_per_batch) {
         const int rows = p.rows_per_batch < p.shard.owned_rows - r0 ? p.rows_per_batch : p.shard.owned_rows - r0;
         const int tile_base = r0 * p.shard.tiles_x;
@@ -1150,17 +1162,17 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t e
         hipLaunchKernelGGL(plan_units_kernel, dim3(batch_tiles), dim3(64), 0, stream, p.scene, p, tile_base, batch_tiles);
         const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
         if (p.scene_in_lds && !p.scene_posed) {
-            hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewLdsUnposed>(p, stream, dyn);
         } else if (p.scene_in_lds) {
-            hipLaunchKernelGGL(primary_kernel<kViewLds>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            hipLaunchKernelGGL(primary_kernel<kViewLds>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewLds>(p, stream, dyn);
         } else {
-            hipLaunchKernelGGL(primary_kernel<kViewHbm>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.tile_rng, out, p, tile_base, batch_tiles);
+            hipLaunchKernelGGL(primary_kernel<kViewHbm>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.tile_rng, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewHbm>(p, stream, 0);
         }
         const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
-        hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, out, p);
+        hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, out, out8, p);
     }
     if (ev_k1) (void)hipEventRecord(ev_k1, stream);
     return hipGetLastError();

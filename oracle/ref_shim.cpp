@@ -428,6 +428,29 @@ void mcref_quantize(const float* rgba, uint8_t* out, size_t n_pixels) {
     }
 }
 
+// The reference's PNG hand-off, for checking the build's store-only PNG writer: ImageWriter::writePNG
+// (image_writer.cpp:6-28) and Image::load (image.cpp:8-25, the vendored stb decoder + /255.0f).
+int mcref_write_png(const char* path, const float* rgba, int w, int h) {
+    Image img(w, h);
+    for (size_t i = 0; i < static_cast<size_t>(w) * h; ++i)
+        img.pixels[i] = Color(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]);
+    return ImageWriter::writePNG(img, path) ? 1 : 0;
+}
+int mcref_load_png(const char* path, float* out_rgba, int capacity_pixels, int* w, int* h) {
+    std::optional<Image> img = Image::load(path);
+    if (!img) return 0;
+    *w = img->width;
+    *h = img->height;
+    if (static_cast<long long>(img->width) * img->height > capacity_pixels) return 0;
+    for (size_t i = 0; i < img->pixels.size(); ++i) {
+        out_rgba[4 * i + 0] = img->pixels[i].r;
+        out_rgba[4 * i + 1] = img->pixels[i].g;
+        out_rgba[4 * i + 2] = img->pixels[i].b;
+        out_rgba[4 * i + 3] = img->pixels[i].a;
+    }
+    return 1;
+}
+
 // SkinParser::parse + MeshBuilder::buildScene through the reference's own code.  The skin is
 // written as a PNG with the reference's vendored stb and parsed back, exactly the app's path.
 int mcref_build_skin_scene(const uint8_t* rgba8, int w, int h, const float pose[12],

@@ -4,6 +4,7 @@
 // the cases that render; without it only the host-side behaviour is exercised.
 #ifdef MCRT_USE_REFERENCE_HEADERS
 #include "raytracer/tile_renderer.h"
+#include "output/image_writer.h"
 #else
 #include "mcskin_types.hpp"
 #endif
@@ -11,6 +12,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 
 static int failures = 0;
@@ -134,6 +136,27 @@ int main(int argc, char** argv) {
                 else restUntouched = restUntouched && p == Color();
             }
         CHECK(tileSame && restUntouched && TileRenderer::lastErrors().empty());
+    }
+    // ImageWriter::writePNG — test_image_writer.cpp: empty image and bad path → false; a valid image
+    // → a PNG file that starts with the PNG signature and carries the IHDR dimensions
+    {
+        CHECK(!ImageWriter::writePNG(Image(), "/tmp/mcrt_drop_in_empty.png"));
+        Image img(5, 3);
+        for (size_t i = 0; i < img.pixels.size(); ++i) img.pixels[i] = Color(0.1f * static_cast<float>(i % 7), 1.5f, -0.25f, 1.0f);
+        CHECK(!ImageWriter::writePNG(img, "/nonexistent_dir_mcrt/x.png"));
+        const std::string path = "/tmp/mcrt_drop_in_" + std::to_string(static_cast<long long>(std::hash<std::string>{}(__FILE__) % 100000)) + ".png";
+        CHECK(ImageWriter::writePNG(img, path));
+        FILE* f = std::fopen(path.c_str(), "rb");
+        CHECK(f != nullptr);
+        if (f) {
+            unsigned char head[24] = {0};
+            CHECK(std::fread(head, 1, 24, f) == 24u);
+            std::fclose(f);
+            std::remove(path.c_str());
+            const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+            CHECK(std::memcmp(head, sig, 8) == 0 && std::memcmp(head + 12, "IHDR", 4) == 0);
+            CHECK(head[19] == 5 && head[23] == 3);
+        }
     }
     std::printf("%s: %d failure(s)\n", gpu ? "gpu" : "host", failures);
     return failures ? 1 : 0;

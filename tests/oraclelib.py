@@ -162,6 +162,23 @@ class Reference(CpuLib):
         self._f("scene_desc_free")(out)
         return d
 
+    def write_png(self, path: str, image: np.ndarray) -> bool:
+        """ImageWriter::writePNG of the reference (quantise + stbi_write_png)."""
+        img = np.ascontiguousarray(image, np.float32)
+        f = self._f("write_png")
+        f.argtypes = [C.c_char_p, abi.c_float_p, C.c_int, C.c_int]
+        return bool(f(os.fsencode(path), abi.fptr(img), img.shape[1], img.shape[0]))
+
+    def load_png(self, path: str, max_pixels: int = 1 << 24):
+        """Image::load of the reference (stb decoder, /255.0f) → (H, W, 4) float32 or None."""
+        buf = np.zeros(max_pixels * 4, np.float32)
+        w, h = C.c_int(), C.c_int()
+        f = self._f("load_png")
+        f.argtypes = [C.c_char_p, abi.c_float_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if not f(os.fsencode(path), abi.fptr(buf), max_pixels, C.byref(w), C.byref(h)):
+            return None
+        return buf[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()
+
     def builtin_pose(self, index: int) -> np.ndarray:
         out = np.zeros(12, np.float32)
         if self._f("builtin_pose")(index, abi.fptr(out)) != 0:

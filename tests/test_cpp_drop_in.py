@@ -16,7 +16,7 @@ REF = "/root/reference/src"
 def build(tmp_path, with_reference: bool) -> str:
     exe = str(tmp_path / ("drop_in_ref" if with_reference else "drop_in"))
     cmd = ["g++", "-std=c++17", "-O1", f"-I{ROOT}/include", f"-I{HOST}", os.path.join(ROOT, "tests", "cpp", "test_drop_in.cpp"),
-           os.path.join(HOST, "tile_renderer_hip.cpp"), f"-L{PKG}", "-lmcrt", f"-Wl,-rpath,{PKG}", "-o", exe]
+           os.path.join(HOST, "tile_renderer_hip.cpp"), os.path.join(HOST, "image_writer_hip.cpp"), f"-L{PKG}", "-lmcrt", f"-Wl,-rpath,{PKG}", "-o", exe]
     if with_reference:
         cmd[3:3] = ["-DMCRT_USE_REFERENCE_HEADERS", f"-I{REF}"]
     subprocess.check_call(cmd)
