@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU session that produces everything profiles/<tag>/ holds.   usage: tools/collect_profiles.sh <tag>
+# (run through gpurun; results land in gpurun_out/<tag>/ — copy what is to be judged into profiles/<tag>/)
+set -u
+TAG=${1:-prof}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err || echo "bench failed"
+cd /tmp
+# the same bench command under the kernel tracer (lanes as shipped: kernels of two lanes overlap)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/trace_bench.log 2>&1
+python3 $R/tools/trace_summary.py $O/trace_bench 40 > $O/kernel_timeline_bench.txt 2>&1
+# one lane: the plain dependency chain of a frame, kernel by kernel
+MCRT_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_1lane -- python3 $R/tools/gpu_case.py base 10 > $O/trace_1lane.log 2>&1
+python3 $R/tools/trace_summary.py $O/trace_1lane 16 > $O/kernel_timeline_1lane.txt 2>&1
+# counters, one lane so that dispatches line up across passes
+MCRT_LANES=1 PMC_SETS=all $R/tools/pmc_run.sh gpurun_out/$TAG/pmc tools/gpu_case.py base 1 > $O/pmc_dispatches.txt 2>&1
+cp $O/trace_bench/*/*kernel_stats.csv $O/kernel_stats_bench.csv 2>/dev/null
+cp $O/trace_1lane/*/*kernel_stats.csv $O/kernel_stats_1lane.csv 2>/dev/null
+ls $O
+cat $O/bench.json
