@@ -84,6 +84,8 @@ def main() -> None:
                     help="gloo: rehearsal of the N>1 logic where RCCL cannot run (gathers through host memory)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares bit-for-bit")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frames rendered concurrently (round-robin scene handles/streams/buffers); 1 = one frame at a time")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,55 +118,70 @@ def main() -> None:
     w, h, bounces, spp, skin, pose = WORKLOADS[args.workload]
     cfg = M.Config(width=w, height=h, maxBounces=bounces, samplesPerPixel=spp)
     sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
-    scene = M.DeviceScene(sd, device=local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    # F frames in flight: frame k is rendered by scene handle / stream / buffers k mod F.  One frame's
+    # pipeline is a chain of ~16 dependent kernels with ~0.2 ms of fixed latency; a renderer that
+    # produces a sequence of frames overlaps the chain of one frame with the dense kernels of the
+    # next.  Every frame is rendered completely; `latency_ms` below is the one-frame-at-a-time figure.
+    F = max(1, args.frames_in_flight)
+    scenes_ = [M.DeviceScene(sd, device=local_rank) for _ in range(F)]
+    if F > 1:  # the frames in flight already fill the chip (and the hardware queues): one stream per frame
+        for sc_ in scenes_:
+            sc_.set_lanes(1)
+    scene = scenes_[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
+    frames = [torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(F if world == 1 or rank == 0 else 0)]
+    frame = frames[0] if frames else None
 
-    frame = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
     if world == 1:
         def step(k: int) -> None:
-            scene.render_device(cfg, frame.data_ptr(), 0, 1, abi.LAYOUT_FRAME, stream)
+            slot = k % F
+            scenes_[slot].render_device(cfg, frames[slot].data_ptr(), 0, 1, abi.LAYOUT_FRAME, streams[slot].cuda_stream)
 
         def drain() -> None:
             pass
     else:
+        from collections import deque
         tiles_y = (h + cfg.tileSize - 1) // cfg.tileSize
         max_rows = ((tiles_y + world - 1) // world) * cfg.tileSize  # padded so every rank sends the same count
-        packed = [torch.empty((max_rows, w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-        gathered = [[torch.empty((max_rows, w, 4), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
-        pending = []
-
-        def finish(k: int, work) -> None:
-            work.wait()
-            if rank == 0:
-                for r in range(world):
-                    M.unpack_rows_device(cfg, r, world, gathered[k & 1][r].data_ptr(), frame.data_ptr(), stream)
-
+        packed = [torch.empty((max_rows, w, 4), dtype=torch.float32, device=dev) for _ in range(F)]
+        # rank 0: one contiguous [world, rows, W, 4] buffer per slot; the gather fills its per-rank views
+        gathered = [torch.empty((world, max_rows, w, 4), dtype=torch.float32, device=dev) for _ in range(F)] if rank == 0 else []
+        pending = deque()
         host_gather = args.dist_backend == "gloo"
 
         class _Done:
             def wait(self):
                 return None
 
+        def finish(k: int, slot: int, work) -> None:
+            with torch.cuda.stream(streams[slot]):
+                work.wait()
+                if rank == 0:  # one launch un-permutes every rank's rows
+                    M.assemble_frame_device(cfg, world, gathered[slot].data_ptr(), max_rows * w, frames[slot].data_ptr(),
+                                            streams[slot].cuda_stream)
+
         def step(k: int) -> None:
-            buf = packed[k & 1]
-            scene.render_device(cfg, buf.data_ptr(), rank, world, abi.LAYOUT_PACKED, stream)
-            if host_gather:  # rehearsal path: same sharding/unpack logic, collective through host memory
-                cpu = buf.cpu()
-                outs = [torch.empty_like(cpu) for _ in range(world)] if rank == 0 else None
-                dist.gather(cpu, outs, dst=0)
-                if rank == 0:
-                    for r in range(world):
-                        gathered[k & 1][r].copy_(outs[r])
-                work = _Done()
-            else:
-                work = dist.gather(buf, gathered[k & 1] if rank == 0 else None, dst=0, async_op=True)
-            if pending:
-                finish(*pending.pop())
-            pending.append((k, work))
+            slot = k % F
+            if len(pending) == F:  # step k - F used this slot: its gather must be done before the buffers are reused
+                finish(*pending.popleft())
+            with torch.cuda.stream(streams[slot]):
+                buf = packed[slot]
+                scenes_[slot].render_device(cfg, buf.data_ptr(), rank, world, abi.LAYOUT_PACKED, streams[slot].cuda_stream)
+                if host_gather:  # rehearsal path: same sharding/assembly logic, collective through host memory
+                    cpu = buf.cpu()
+                    outs = [torch.empty_like(cpu) for _ in range(world)] if rank == 0 else None
+                    dist.gather(cpu, outs, dst=0)
+                    if rank == 0:
+                        for r in range(world):
+                            gathered[slot][r].copy_(outs[r])
+                    work = _Done()
+                else:
+                    work = dist.gather(buf, list(gathered[slot].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+            pending.append((k, slot, work))
 
         def drain() -> None:
             while pending:
-                finish(*pending.pop())
+                finish(*pending.popleft())
 
     def sync() -> None:
         torch.cuda.synchronize()
@@ -187,6 +204,22 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # one frame at a time (rank-local render only): enqueue, wait, repeat — with the library's own
+    # lane split, which is what a caller rendering single frames gets
+    scene.set_lanes(0)
+    lat_n = max(5, min(args.steps, 30))
+    lat_target = frames[0] if world == 1 else packed[0]
+    torch.cuda.synchronize()
+    t_lat = time.perf_counter()
+    for _ in range(lat_n):
+        if world == 1:
+            scene.render_device(cfg, lat_target.data_ptr(), 0, 1, abi.LAYOUT_FRAME, streams[0].cuda_stream)
+        else:
+            scene.render_device(cfg, lat_target.data_ptr(), rank, world, abi.LAYOUT_PACKED, streams[0].cuda_stream)
+        torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - t_lat) / lat_n * 1e3
+    stream = streams[0].cuda_stream
+
     # kernel-only duration of the dominant (trace) kernel: hipEvents on the launch stream
     first, stepn = (0, 1) if world == 1 else (rank, world)
     layout = abi.LAYOUT_FRAME if world == 1 else abi.LAYOUT_PACKED
@@ -199,7 +232,7 @@ def main() -> None:
         whole = torch.empty_like(frame)
         scene.render_device(cfg, whole.data_ptr(), 0, 1, abi.LAYOUT_FRAME, stream)
         torch.cuda.synchronize()
-        check = bool(torch.equal(whole, frame))
+        check = all(bool(torch.equal(whole, f)) for f in frames[:min(F, args.steps + args.warmup)])
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -232,7 +265,9 @@ def main() -> None:
                 "workload": f"{w}x{h}, {bounces} bounces, {spp} spp, 1 light, synthetic 64x{64 if skin == 'S64' else 32} skin ({skin}), pose {pose}, soft shadows 8, tile 32",
                 "name": args.workload,
                 "parallelism": "single GPU" if world == 1 else f"cyclic tile rows over {world} GPUs + RCCL gather to rank 0 (overlapped)",
+                "frames_in_flight": F,
             },
+            "latency_ms": round(latency_ms, 4),
             "kernel": {"pipeline_ms": round(trace_ms, 4),
                        "note": "hipEvents on the launch stream around one frame's whole pipeline (seed, plan, primary, light_samples, "
                                "[shadow, shade] x levels, resolve; 2 lanes fork/join inside); per-kernel split: profiles/"},
@@ -257,7 +292,8 @@ def main() -> None:
                 line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
 
-    scene.close()
+    for sc_ in scenes_:
+        sc_.close()
     if world > 1:
         dist.destroy_process_group()
 

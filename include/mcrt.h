@@ -154,6 +154,12 @@ void mcrt_scene_destroy(mcrt_scene* scene);
 int mcrt_render_device(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_first,
                        int tile_row_step, int out_layout, float* d_out_rgba, void* stream);
 
+/* A render is spread over internal *lanes* (streams with their own workspace, every n-th tile row of
+ * the shard each, forked from / joined to the caller's stream) when the shard is large enough.
+ * lanes = 0 restores that automatic choice, lanes >= 1 forces a count (at most 4).  A caller that
+ * already keeps several frames in flight on its own streams should use 1. */
+int mcrt_scene_set_lanes(mcrt_scene* scene, int lanes);
+
 /* Same render with the quantisation fused into the epilogue: writes the float4 frame to d_out_f32
  * and/or `(uint8_t)(clamp(c,0,1)*255.0f+0.5f)` per channel to d_out_rgba8 (either may be NULL, not
  * both) — the RGBA8 plane is what ImageWriter::writePNG hands to the PNG encoder
@@ -168,6 +174,12 @@ int mcrt_owned_pixel_rows(const mcrt_config* cfg, int tile_row_first, int tile_r
  * Used by the gather root after the RCCL gather. */
 int mcrt_unpack_rows_device(const mcrt_config* cfg, int tile_row_first, int tile_row_step,
                             const float* d_packed, float* d_frame, void* stream);
+
+/* The same for all ranks of a gather in one launch: d_gathered holds `world` packed buffers (rank r
+ * rendered with first=r, step=world), rank_stride_pixels float4 apart (>= the padded packed size
+ * ceil(tile_rows/world) * tile_size * width). */
+int mcrt_assemble_frame_device(const mcrt_config* cfg, int world, const float* d_gathered, size_t rank_stride_pixels,
+                               float* d_frame, void* stream);
 
 /* float RGBA → RGBA8, `(uint8_t)(clamp(c,0,1)*255.0f+0.5f)` per channel
  * (/root/reference/src/output/image_writer.cpp:18-22 ≡ src/skin/image.cpp:31-36). */

@@ -3,6 +3,7 @@ from .abi import Config, Mesh, Scene, Texture  # noqa: F401
 from .skins import synthetic_skin  # noqa: F401
 from .api import (  # noqa: F401
     DeviceScene,
+    assemble_frame_device,
     ImageWriter,
     MeshBuilder,
     SceneDesc,
@@ -22,5 +23,5 @@ from .api import (  # noqa: F401
 __all__ = [
     "Config", "Mesh", "Scene", "Texture", "synthetic_skin", "DeviceScene", "MeshBuilder", "SceneDesc",
     "TileRenderer", "device_count", "flatten", "getBuiltinPoses", "probe_detmath", "probe_detmath_range",
-    "probe_mt_uniform", "quantize_rgba8", "quantize_rgba8_device", "unpack_rows_device", "ImageWriter", "render_png",
+    "probe_mt_uniform", "quantize_rgba8", "quantize_rgba8_device", "unpack_rows_device", "ImageWriter", "render_png", "assemble_frame_device",
 ]

@@ -209,6 +209,10 @@ class DeviceScene:
         except Exception:
             pass
 
+    def set_lanes(self, lanes: int) -> None:
+        """0 = automatic split of a render over internal streams, n >= 1 = exactly n (mcrt_scene_set_lanes)."""
+        check(load().mcrt_scene_set_lanes(self._h, int(lanes)))
+
     def owned_pixel_rows(self, config: Config, first: int = 0, step: int = 1) -> int:
         c = config.to_c()
         return int(load().mcrt_owned_pixel_rows(C.byref(c), first, step))
@@ -252,6 +256,14 @@ class DeviceScene:
 def unpack_rows_device(config: Config, first: int, step: int, packed_ptr: int, frame_ptr: int, stream: int = 0) -> None:
     c = config.to_c()
     check(load().mcrt_unpack_rows_device(C.byref(c), first, step, C.c_void_p(packed_ptr), C.c_void_p(frame_ptr), C.c_void_p(stream)))
+
+
+def assemble_frame_device(config: Config, world: int, gathered_ptr: int, rank_stride_pixels: int, frame_ptr: int,
+                          stream: int = 0) -> None:
+    """All ranks' packed rows (one contiguous [world, packed_rows, W, 4] buffer) → the frame, one launch."""
+    c = config.to_c()
+    check(load().mcrt_assemble_frame_device(C.byref(c), world, C.c_void_p(gathered_ptr), rank_stride_pixels,
+                                            C.c_void_p(frame_ptr), C.c_void_p(stream)))
 
 
 def quantize_rgba8_device(rgba_ptr: int, out_ptr: int, n_pixels: int, stream: int = 0) -> None:

@@ -108,6 +108,7 @@ struct mcrt_scene {
     bool posed = false;  // any mesh with MESH_ROTATED
     DeviceBuffer blob;
     Lane lanes[kMaxLanes];
+    int forced_lanes = 0;  // mcrt_scene_set_lanes: 0 = automatic
     hipEvent_t fork = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -129,13 +130,15 @@ size_t workspace_budget() {
 }
 
 // lanes for a shard: enough work per lane that the extra launches pay (MCRT_LANES forces a count)
-int lane_count(const mcrt_config& cfg, const Shard& sh) {
+int lane_count(const mcrt_scene* s, const mcrt_config& cfg, const Shard& sh) {
     static const int forced = [] {
         const char* e = std::getenv("MCRT_LANES");
         return e ? std::atoi(e) : 0;
     }();
     int lanes;
-    if (forced > 0) {
+    if (s->forced_lanes > 0) {
+        lanes = s->forced_lanes;
+    } else if (forced > 0) {
         lanes = forced;
     } else {
         const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
@@ -210,7 +213,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
                    hipStream_t stream) {
     const Shard whole = make_shard(*cfg, first, step);
     if (whole.owned_rows <= 0) return MCRT_OK;
-    const int n_lanes = lane_count(*cfg, whole);
+    const int n_lanes = lane_count(s, *cfg, whole);
     RenderParams p[kMaxLanes];
     for (int li = 0; li < n_lanes; ++li) {
         int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li]);
@@ -346,6 +349,12 @@ void mcrt_scene_destroy(mcrt_scene* s) {
     delete s;
 }
 
+int mcrt_scene_set_lanes(mcrt_scene* s, int lanes) {
+    if (!s || lanes < 0) return fail(MCRT_ERR_INVALID, "bad argument");
+    s->forced_lanes = lanes;
+    return MCRT_OK;
+}
+
 int mcrt_owned_pixel_rows(const mcrt_config* cfg, int first, int step) {
     if (!cfg || !valid_frame(cfg)) return 0;
     Shard sh = make_shard(*cfg, first, step);
@@ -400,6 +409,17 @@ int mcrt_unpack_rows_device(const mcrt_config* cfg, int first, int step, const f
     if (!valid_frame(cfg)) return MCRT_OK;
     Shard sh = make_shard(*cfg, first, step);
     HIP_TRY(launch_unpack_rows(*cfg, sh, d_packed, d_frame, static_cast<hipStream_t>(stream)));
+    return MCRT_OK;
+}
+
+int mcrt_assemble_frame_device(const mcrt_config* cfg, int world, const float* d_gathered, size_t rank_stride_pixels,
+                               float* d_frame, void* stream) {
+    if (!cfg || !d_gathered || !d_frame || world < 1) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (!valid_frame(cfg)) return MCRT_OK;
+    const int tiles_y = (cfg->height + cfg->tile_size - 1) / cfg->tile_size;
+    const size_t need = static_cast<size_t>((tiles_y + world - 1) / world) * cfg->tile_size * cfg->width;
+    if (world > 1 && rank_stride_pixels < need) return fail(MCRT_ERR_INVALID, "rank stride smaller than a rank's packed rows");
+    HIP_TRY(launch_assemble_frame(*cfg, world, d_gathered, rank_stride_pixels, d_frame, static_cast<hipStream_t>(stream)));
     return MCRT_OK;
 }
 

@@ -84,6 +84,8 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t e
 
 hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const float* packed, float* frame,
                               hipStream_t stream);
+hipError_t launch_assemble_frame(const mcrt_config& cfg, int world, const float* gathered, size_t rank_stride_pixels,
+                                 float* frame, hipStream_t stream);
 hipError_t launch_quantize(const float* rgba, uint8_t* out, size_t n_pixels, hipStream_t stream);
 
 // probes

@@ -962,6 +962,20 @@ __global__ void unpack_rows_kernel(mcrt_config cfg, Shard sh, const float4* pack
     frame[static_cast<size_t>(y) * W + x] = packed[i];
 }
 
+// every rank's packed rows (rank-major, `rank_stride` float4 apart) → the frame, one thread per output
+// pixel: tile row r belongs to rank r mod world and is that rank's (r div world)-th packed tile row
+__global__ void assemble_frame_kernel(mcrt_config cfg, int world, const float4* __restrict__ gathered, size_t rank_stride,
+                                      float4* __restrict__ frame) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int W = cfg.width, T = cfg.tile_size;
+    if (i >= static_cast<size_t>(W) * cfg.height) return;
+    const int y = static_cast<int>(i / W);
+    const int x = static_cast<int>(i - static_cast<size_t>(y) * W);
+    const int r = y / T, ly = y - r * T;
+    const int rank = r % world, k = r / world;
+    frame[i] = gathered[static_cast<size_t>(rank) * rank_stride + (static_cast<size_t>(k) * T + ly) * W + x];
+}
+
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, size_t n) {  // image_writer.cpp:18-22
     size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1184,6 +1198,15 @@ hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const flo
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(unpack_rows_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, cfg, sh,
                        reinterpret_cast<const float4*>(packed), reinterpret_cast<float4*>(frame));
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_frame(const mcrt_config& cfg, int world, const float* gathered, size_t rank_stride_pixels,
+                                 float* frame, hipStream_t stream) {
+    const size_t n = static_cast<size_t>(cfg.width) * cfg.height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(assemble_frame_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, cfg, world,
+                       reinterpret_cast<const float4*>(gathered), rank_stride_pixels, reinterpret_cast<float4*>(frame));
     return hipGetLastError();
 }
 

@@ -227,3 +227,29 @@ def test_lanes_render_the_same_frame(mcrt, gpu, tmp_path):
     cfg = abi.Config(width=333, height=250, maxBounces=3, samplesPerPixel=4, tileSize=16)
     sd = scenes.skin_scene("S64", 6)
     scenes.assert_bit_equal(base["frame"], oraclelib.Oracle().render(sd.ptr, cfg), "lanes render vs oracle")
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_assemble_frame_equals_per_rank_unpack(mcrt, gpu, world):
+    """The gather root's single-launch assembly of all ranks' packed rows gives the frame that the
+    per-rank un-permute gives, and both equal the whole-frame render."""
+    import torch
+
+    cfg = abi.Config(width=250, height=170, maxBounces=2, samplesPerPixel=2, tileSize=16)
+    ds = mcrt.DeviceScene(scenes.skin_scene("S64", 3))
+    st = torch.cuda.current_stream().cuda_stream
+    whole = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda")
+    ds.render_device(cfg, whole.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st)
+    tiles_y = (cfg.height + cfg.tileSize - 1) // cfg.tileSize
+    max_rows = ((tiles_y + world - 1) // world) * cfg.tileSize
+    gathered = torch.full((world, max_rows, cfg.width, 4), -7.0, dtype=torch.float32, device="cuda")
+    for r in range(world):
+        ds.render_device(cfg, gathered[r].data_ptr(), r, world, abi.LAYOUT_PACKED, st)
+    a = torch.zeros_like(whole)
+    b = torch.zeros_like(whole)
+    mcrt.assemble_frame_device(cfg, world, gathered.data_ptr(), max_rows * cfg.width, a.data_ptr(), st)
+    for r in range(world):
+        mcrt.unpack_rows_device(cfg, r, world, gathered[r].data_ptr(), b.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(a, whole) and torch.equal(b, whole)
+    ds.close()

@@ -31,11 +31,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ds.render_device(cfg, frame.data_ptr(), 0, 1, abi.LAYOUT_FRAME, h)
         torch.cuda.synchronize()
     lat = (time.perf_counter() - t0) / n * 1e3
-    print(f"{case} lanes={os.environ.get('MCRT_LANES','auto')} budget_mb={os.environ.get('MCRT_WORKSPACE_MB','default')}: back-to-back {thr:.4f} ms/frame, synced {lat:.4f} ms/frame")
+    print(f"{case} lanes={os.environ.get('MCRT_LANES','auto')} split={os.environ.get('MCRT_LANE_SPLIT','1')} stagger={os.environ.get('MCRT_LANE_STAGGER','0')}: back-to-back {thr:.4f} ms/frame, synced {lat:.4f} ms/frame")
     sys.exit(0)
 case = sys.argv[1]
+extra = dict(kv.split("=") for kv in sys.argv[4:])
 for budget in sys.argv[3].split(","):
     for lanes in sys.argv[2].split(","):
-        env = dict(os.environ, MCRT_LANES=lanes, MCRT_WORKSPACE_MB=budget)
+        env = dict(os.environ, MCRT_LANES=lanes, MCRT_WORKSPACE_MB=budget, **extra)
         r = subprocess.run([sys.executable, __file__, "child", case], env=env, capture_output=True, text=True, timeout=300)
         print((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
