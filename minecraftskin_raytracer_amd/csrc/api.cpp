@@ -109,6 +109,18 @@ struct mcrt_scene {
     DeviceBuffer blob;
     Lane lanes[kMaxLanes];
     int forced_lanes = 0;  // mcrt_scene_set_lanes: 0 = automatic
+    // recorded launch sequences of recent renders (hipGraph), replayed when the parameters repeat
+    struct Recorded {
+        int n_lanes = 0;
+        RenderParams p[kMaxLanes];
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        unsigned long long last_use = 0;
+    };
+    static constexpr int kRecorded = 4;
+    Recorded recorded[kRecorded];
+    unsigned long long use_clock = 0;
+    hipStream_t capture_stream = nullptr;
     hipEvent_t fork = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -208,22 +220,8 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     return MCRT_OK;
 }
 
-// enqueue one render of the shard (first, step) on `stream`: lanes fork from and join the stream
-int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, uint8_t* d_out8,
-                   hipStream_t stream) {
-    const Shard whole = make_shard(*cfg, first, step);
-    if (whole.owned_rows <= 0) return MCRT_OK;
-    const int n_lanes = lane_count(s, *cfg, whole);
-    RenderParams p[kMaxLanes];
-    for (int li = 0; li < n_lanes; ++li) {
-        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li]);
-        if (rc != MCRT_OK) return rc;
-        Lane& ln = s->lanes[li];
-        if (li > 0 && !ln.stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-        }
-    }
+// the launches of one render on `stream`: lanes fork from and join the stream
+int launch_lanes(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream) {
     if (n_lanes > 1) {
         if (!s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(s->fork, stream));
@@ -236,6 +234,98 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     }
     HIP_TRY(launch_render(p[0], stream, nullptr, nullptr));
     for (int li = 1; li < n_lanes; ++li) HIP_TRY(hipStreamWaitEvent(stream, s->lanes[li].done, 0));
+    return MCRT_OK;
+}
+
+// MCRT_GRAPH=0 turns launch recording off (every render then issues its ~17 launches per lane)
+bool graphs_enabled() {
+    static const bool v = [] {
+        const char* e = std::getenv("MCRT_GRAPH");
+        return !e || std::atoi(e) != 0;
+    }();
+    return v;
+}
+
+// enqueue one render of the shard (first, step) on `stream`.  The launch sequence of a render is a
+// pure function of its RenderParams (all control flow that depends on data lives on the device), so
+// it is recorded once as a hipGraph — through stream capture on a private stream, lanes included —
+// and replayed with a single hipGraphLaunch whenever the same parameters come again: ~75 us of
+// launch calls per render become one.
+int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, uint8_t* d_out8,
+                   hipStream_t stream) {
+    const Shard whole = make_shard(*cfg, first, step);
+    if (whole.owned_rows <= 0) return MCRT_OK;
+    const int n_lanes = lane_count(s, *cfg, whole);
+    RenderParams p[kMaxLanes];
+    std::memset(p, 0, sizeof p);
+    for (int li = 0; li < n_lanes; ++li) {
+        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li]);
+        if (rc != MCRT_OK) return rc;
+        Lane& ln = s->lanes[li];
+        if (li > 0 && !ln.stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        }
+    }
+    if (n_lanes > 1 && !s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+    if (!graphs_enabled()) return launch_lanes(s, p, n_lanes, stream);
+
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return launch_lanes(s, p, n_lanes, stream);  // the caller is recording a graph of its own
+
+    ++s->use_clock;
+    mcrt_scene::Recorded* slot = nullptr;
+    for (auto& r : s->recorded)
+        if (r.exec && r.n_lanes == n_lanes && std::memcmp(r.p, p, sizeof(RenderParams) * n_lanes) == 0) slot = &r;
+    if (!slot) {
+        // a parameter set is recorded the second time it is seen; one-off renders launch directly
+        mcrt_scene::Recorded* victim = &s->recorded[0];
+        for (auto& r : s->recorded) {
+            if (!r.exec && r.n_lanes == n_lanes && std::memcmp(r.p, p, sizeof(RenderParams) * n_lanes) == 0) {
+                victim = &r;  // seen once before: record now
+                slot = victim;
+                break;
+            }
+            if (r.last_use < victim->last_use) victim = &r;
+        }
+        if (!slot) {  // first sighting: remember the parameters, launch directly
+            if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
+            if (victim->graph) (void)hipGraphDestroy(victim->graph);
+            victim->exec = nullptr;
+            victim->graph = nullptr;
+            victim->n_lanes = n_lanes;
+            std::memcpy(victim->p, p, sizeof p);
+            victim->last_use = s->use_clock;
+            return launch_lanes(s, p, n_lanes, stream);
+        }
+        if (!s->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
+        hipError_t e = hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            const int rc = launch_lanes(s, p, n_lanes, s->capture_stream);
+            hipGraph_t g = nullptr;
+            e = hipStreamEndCapture(s->capture_stream, &g);
+            if (rc == MCRT_OK && e == hipSuccess && g) {
+                hipGraphExec_t ex = nullptr;
+                e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+                if (e == hipSuccess && ex) {
+                    slot->graph = g;
+                    slot->exec = ex;
+                } else {
+                    (void)hipGraphDestroy(g);
+                }
+            } else if (g) {
+                (void)hipGraphDestroy(g);
+            }
+        }
+        if (!slot->exec) {  // recording failed: forget it and launch directly
+            (void)hipGetLastError();
+            slot->n_lanes = 0;
+            return launch_lanes(s, p, n_lanes, stream);
+        }
+    }
+    slot->last_use = s->use_clock;
+    HIP_TRY(hipGraphLaunch(slot->exec, stream));
     return MCRT_OK;
 }
 
@@ -343,6 +433,11 @@ void mcrt_scene_destroy(mcrt_scene* s) {
         if (ln.done) (void)hipEventDestroy(ln.done);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
+    for (auto& r : s->recorded) {
+        if (r.exec) (void)hipGraphExecDestroy(r.exec);
+        if (r.graph) (void)hipGraphDestroy(r.graph);
+    }
+    if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     if (s->fork) (void)hipEventDestroy(s->fork);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);

@@ -17,6 +17,7 @@ CASES = {
     "gui_ao": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=4, aoEnabled=True, aoSamples=16)),
     "gui_dof": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=4, dofEnabled=True, aperture=0.3)),
     "spp64": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=64)),
+    "tiny": (lambda: scenes.skin_scene("S64", 0), dict(width=64, height=64, maxBounces=4, samplesPerPixel=4)),
     "4k": (lambda: scenes.skin_scene("S64", 0), dict(width=3840, height=2160, maxBounces=8, samplesPerPixel=16)),
 }
 name = sys.argv[1]
