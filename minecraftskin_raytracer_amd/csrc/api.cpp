@@ -109,6 +109,7 @@ struct mcrt_scene {
     DeviceBuffer blob;
     Lane lanes[kMaxLanes];
     int forced_lanes = 0;  // mcrt_scene_set_lanes: 0 = automatic
+    size_t budget = 0;     // current workspace budget (0 = workspace_budget()); halved when the device is short of memory
     // recorded launch sequences of recent renders (hipGraph), replayed when the parameters repeat
     struct Recorded {
         int n_lanes = 0;
@@ -181,21 +182,44 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     p.scene_posed = sc->posed ? 1 : 0;
     p.lds_alpha_words = fits ? static_cast<int>(sc->alpha_words) : 0;
     p.lds_face_entries = fits ? static_cast<int>(sc->n_meshes * 6) : 0;
-    const WorkspaceBytes w = plan_workspace(p, target_units(), workspace_budget() / static_cast<size_t>(n_lanes));
-    HIP_TRY(s->tile_rng.reserve(w.tile_rng));
-    HIP_TRY(s->scol.reserve(w.scol));
-    HIP_TRY(s->units.reserve(w.units));
-    HIP_TRY(s->tile_mask.reserve(w.tile_mask));
-    HIP_TRY(s->unit_hits[0].reserve(w.unit_hits));
-    HIP_TRY(s->unit_hits[1].reserve(w.unit_hits));
-    for (auto& q : s->queues) HIP_TRY(q.reserve(w.queue_each));
-    HIP_TRY(s->targets.reserve(w.targets));
-    HIP_TRY(s->lit[0].reserve(w.lit));
-    HIP_TRY(s->lit[1].reserve(w.lit));
-    HIP_TRY(s->stack.reserve(w.stack));
-    HIP_TRY(s->root_sample.reserve(w.root_sample));
-    HIP_TRY(s->counters.reserve(w.counters));
-    HIP_TRY(s->hit_rng.reserve(w.hit_rng));
+    // The budget bounds the batch size; when the device cannot give that much right now (other
+    // allocations, a shared GPU) the budget is halved — down to one tile row per batch — and the
+    // lane's buffers are re-planned, instead of failing the render.
+    WorkspaceBytes w{};
+    for (;;) {
+        if (!sc->budget) sc->budget = workspace_budget();
+        w = plan_workspace(p, target_units(), sc->budget / static_cast<size_t>(n_lanes));
+        hipError_t e = hipSuccess;
+        auto want = [&](DeviceBuffer& b, size_t bytes) {
+            if (e == hipSuccess) e = b.reserve(bytes);
+        };
+        want(s->tile_rng, w.tile_rng);
+        want(s->scol, w.scol);
+        want(s->units, w.units);
+        want(s->tile_mask, w.tile_mask);
+        want(s->unit_hits[0], w.unit_hits);
+        want(s->unit_hits[1], w.unit_hits);
+        for (auto& q : s->queues) want(q, w.queue_each);
+        want(s->targets, w.targets);
+        want(s->lit[0], w.lit);
+        want(s->lit[1], w.lit);
+        want(s->stack, w.stack);
+        want(s->root_sample, w.root_sample);
+        want(s->counters, w.counters);
+        want(s->hit_rng, w.hit_rng);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || p.rows_per_batch <= 1 || sc->budget < (static_cast<size_t>(64) << 20))
+            return hip_fail(e, "workspace allocation");
+        // make room: this lane's partially grown buffers go, then try again with half the budget
+        (void)hipDeviceSynchronize();
+        s->tile_rng.release(), s->scol.release(), s->units.release(), s->tile_mask.release();
+        s->unit_hits[0].release(), s->unit_hits[1].release();
+        for (auto& q : s->queues) q.release();
+        s->targets.release(), s->lit[0].release(), s->lit[1].release(), s->stack.release();
+        s->root_sample.release(), s->counters.release(), s->hit_rng.release();
+        sc->budget /= 2;
+    }
     p.tile_rng = w.tile_rng ? static_cast<uint32_t*>(s->tile_rng.ptr) : nullptr;
     WaveSpace& ws = p.ws;
     ws.scol = static_cast<float4*>(s->scol.ptr);
@@ -427,6 +451,7 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
 void mcrt_scene_destroy(mcrt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();  // renders of this scene may still be running on the caller's streams
     s->blob.release();  // the other buffers are released by their destructors below
     for (auto& ln : s->lanes) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);

@@ -253,3 +253,34 @@ def test_assemble_frame_equals_per_rank_unpack(mcrt, gpu, world):
     torch.cuda.synchronize()
     assert torch.equal(a, whole) and torch.equal(b, whole)
     ds.close()
+
+
+def test_render_survives_a_nearly_full_device(mcrt, gpu):
+    """With most of HBM taken by someone else the workspace budget is halved until the buffers fit;
+    the frame is the same (smaller batches only)."""
+    import torch
+
+    cfg = abi.Config(width=1280, height=720, maxBounces=3, samplesPerPixel=4)
+    sd = scenes.skin_scene("S64", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda")
+    ds = mcrt.DeviceScene(sd)
+    ds.render_device(cfg, ref.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st)
+    torch.cuda.synchronize()
+    ds.close()
+    free, _total = torch.cuda.mem_get_info()
+    leave = 600 << 20  # the unconstrained workspace of this frame is ~1.3 GB
+    hog = torch.empty(max(0, free - leave), dtype=torch.uint8, device="cuda")
+    try:
+        free2, _ = torch.cuda.mem_get_info()
+        assert free2 < (900 << 20)
+        ds2 = mcrt.DeviceScene(sd)
+        # the output frame is carved out of the hog so that it does not compete for the leftover
+        frame = hog[: cfg.height * cfg.width * 16].view(torch.float32).view(cfg.height, cfg.width, 4)
+        ds2.render_device(cfg, frame.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st)
+        torch.cuda.synchronize()
+        assert torch.equal(frame, ref)
+        ds2.close()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
