@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the tile-render hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-in-flight F]
 
 A *step* is one render of the BASELINE.json north-star frame (configs[1]: 1920x1080, 4 bounces,
 4 samples/pixel, one light, synthetic 64x64 skin with inner+outer layer, `RayTracer::Config`
 defaults otherwise) with the flattened scene already resident in HBM; the output is the float4
-framebuffer in HBM.  N > 1 (launched by torch.distributed.run, one process per GPU): the SAME frame
-is sharded by cyclic tile rows (rank r renders tile rows r, r+N, ...), each rank renders into a
-packed buffer and an RCCL gather over xGMI assembles the frame on rank 0 (strong scaling: the total
-work is fixed).  The gather of step k overlaps the render of step k+1.
+framebuffer in HBM.  F frames (default 4) are in flight: step k uses scene handle / stream / output
+buffer k mod F, every frame is rendered completely (`--check` compares each buffer with a lone
+render); `latency_ms` and `kernel.pipeline_ms` report the one-frame-at-a-time figures next to the
+throughput.  N > 1 (launched by torch.distributed.run, one process per GPU): the SAME frame is
+sharded by cyclic tile rows (rank r renders tile rows r, r+N, ...), each rank renders into a packed
+buffer and an RCCL gather over xGMI assembles the frame on rank 0 (strong scaling: the total work
+is fixed); gathers overlap the renders of the following steps.
 
-Rank 0 prints ONE JSON line: metric/value per BASELINE.json plus `roofline` (the trace kernel's
-algorithmic bytes, 16 B per output pixel, over its hipEvent-measured duration — this path is
-VALU-bound; VALU-pipe busy and HBM traffic from the PMC passes are in profiles/) and, at N = 1, `cpu_baseline` (the compiled reference, or the oracle
-port when oracle/_ref is absent, timed on this box's host cores on a bounded sample).
+Rank 0 prints ONE JSON line: metric/value per BASELINE.json plus `roofline` (algorithmic bytes, 16 B
+per output pixel, over the hipEvent-measured duration of one frame's pipeline — this path is
+VALU-bound; VALU-pipe busy and HBM traffic from the PMC passes are in profiles/) and,
+at N = 1, `cpu_baseline` (the compiled reference, or the oracle port when oracle/_ref is absent,
+timed on this box's host cores on a bounded sample).
 """
 from __future__ import annotations
 
@@ -292,7 +296,7 @@ def main() -> None:
                 "traffic": traffic,
                 "kernel": "whole wavefront pipeline of one frame (dominant stage: shadow_kernel, see profiles/)",
                 "note": "algorithmic bytes = 16 B x output pixels per frame; the path is VALU/latency-bound by construction "
-                        "(DESIGN.md): VALU pipe 43 % busy over the frame, 61 % in shadow (profiles/r01_v4)",
+                        "(DESIGN.md): VALU pipe 42 % busy over one frame's chain, 71 % with four frames in flight (profiles/r01_v5)",
             },
         }
         if check is not None:

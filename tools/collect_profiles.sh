@@ -8,9 +8,10 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err || echo "bench failed"
+timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 --check > $O/bench.json 2> $O/bench.err || echo "bench failed"
+timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 --frames-in-flight 1 --no-cpu-baseline > $O/bench_one_frame_at_a_time.json 2>> $O/bench.err || echo "bench F=1 failed"
 cd /tmp
-# the same bench command under the kernel tracer (lanes as shipped: kernels of two lanes overlap)
+# the same bench command under the kernel tracer (four frames in flight: kernels of different frames overlap)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/trace_bench.log 2>&1
 python3 $R/tools/trace_summary.py $O/trace_bench 40 > $O/kernel_timeline_bench.txt 2>&1
 # one lane: the plain dependency chain of a frame, kernel by kernel
