@@ -98,7 +98,7 @@ struct Lane {
     hipStream_t stream = nullptr;  // owned; unused for lane 0
     hipEvent_t done = nullptr;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
-    DeviceBuffer tile_rng, scol, units, unit_hits[2], tile_mask, queues[10], targets, lit[2], stack, root_sample, counters, hit_rng;
+    DeviceBuffer tile_rng, scol, units, unit_hits[2], tile_mask, queues[10], targets, cand, lit[2], stack, root_sample, counters, hit_rng;
 };
 
 struct mcrt_scene {
@@ -201,6 +201,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         want(s->unit_hits[1], w.unit_hits);
         for (auto& q : s->queues) want(q, w.queue_each);
         want(s->targets, w.targets);
+        want(s->cand, w.cand);
         want(s->lit[0], w.lit);
         want(s->lit[1], w.lit);
         want(s->stack, w.stack);
@@ -216,7 +217,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         s->tile_rng.release(), s->scol.release(), s->units.release(), s->tile_mask.release();
         s->unit_hits[0].release(), s->unit_hits[1].release();
         for (auto& q : s->queues) q.release();
-        s->targets.release(), s->lit[0].release(), s->lit[1].release(), s->stack.release();
+        s->targets.release(), s->cand.release(), s->lit[0].release(), s->lit[1].release(), s->stack.release();
         s->root_sample.release(), s->counters.release(), s->hit_rng.release();
         sc->budget /= 2;
     }
@@ -233,6 +234,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         ws.q_t[k] = static_cast<float4*>(s->queues[8 + k].ptr);
     }
     ws.targets = static_cast<float*>(s->targets.ptr);
+    ws.cand = static_cast<unsigned long long*>(s->cand.ptr);
     ws.lit[0] = static_cast<uint32_t*>(s->lit[0].ptr);
     ws.lit[1] = static_cast<uint32_t*>(s->lit[1].ptr);
     ws.unit_hits[0] = static_cast<uint32_t*>(s->unit_hits[0].ptr);

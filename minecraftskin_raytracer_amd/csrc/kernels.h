@@ -37,6 +37,7 @@ struct WaveSpace {
     float4* q_n[2];         //                                         hit normal (as intersectMesh returns it)
     float4* q_t[2];         //                                         texel colour
     float* targets;         // [cap][3*shadowSamples] light sample positions of the current level's hits
+    unsigned long long* cand;  // [cap] per hit: meshes its soft-shadow rays can meet (conservative first pass, once per hit)
     uint32_t* lit[2];       // [cap] visible light samples of a level's hits (ping-pong by level parity)
     float4* stack;          // [cap][stack_stride] level colours of the chain rooted at level-0 entry r
     uint32_t* root_sample;  // [cap] scol slot of the sample that level-0 entry r belongs to
@@ -70,7 +71,7 @@ Shard make_shard(const mcrt_config& cfg, int first, int step);
 // p.ws.cap / p.ws.stack_stride.  budget_bytes bounds the per-batch workspace (a batch is never
 // smaller than one tile row).
 struct WorkspaceBytes {
-    size_t tile_rng, scol, units, unit_hits, tile_mask, queue_each, targets, lit, stack, root_sample, counters, hit_rng;
+    size_t tile_rng, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, root_sample, counters, hit_rng;
 };
 WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_bytes);
 constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels

@@ -612,8 +612,10 @@ __device__ __forceinline__ void seed_light_rng(typename SampleRng<kGeneral>::typ
 }
 
 // 2·S draws of a seeded engine → the S light sample positions of entry e
-template <class Rng>
-__device__ __forceinline__ void write_light_samples(const SceneView& sc, const WaveSpace& ws, uint32_t e, V3 P, int S, Rng& rng) {
+// ... and the hit's bundle mask: which meshes any of its S shadow rays can meet (rt::bundle_candidates)
+template <bool kPosed, class Rng>
+__device__ __forceinline__ void write_light_samples(const SceneView& sc, const WaveSpace& ws, uint32_t e, V3 P, V3 N, int S, Rng& rng) {
+    ws.cand[e] = bundle_candidates<kPosed>(sc, P + N * 1e-3f, ld3(sc.hdr->light_pos), sc.hdr->light_radius);
     const LightFrame frame = light_frame(sc, P);
     float* dst = ws.targets + static_cast<size_t>(e) * 3 * S;
     for (int i = 0; i < S; ++i) {
@@ -626,18 +628,18 @@ __device__ __forceinline__ void write_light_samples(const SceneView& sc, const W
     }
 }
 
-template <bool kGeneral>
-__device__ __forceinline__ void emit_light_samples(const SceneView& sc, const WaveSpace& ws, uint32_t e, V3 P, int depth, int S,
+template <bool kGeneral, bool kPosed>
+__device__ __forceinline__ void emit_light_samples(const SceneView& sc, const WaveSpace& ws, uint32_t e, V3 P, V3 N, int depth, int S,
                                                    uint32_t* my_rng) {
     typename SampleRng<kGeneral>::type rng;
     seed_light_rng<kGeneral>(rng, P, depth, S, my_rng);
-    write_light_samples(sc, ws, e, P, S, rng);
+    write_light_samples<kPosed>(sc, ws, e, P, N, S, rng);
 }
 
 // light_samples: per hit, the 397-step mt19937 seeding recurrence (sequential), then its 2·S
 // draws turned into the S light sample positions.  One hit per lane: thousands of resident waves
 // hide the integer chain, and the S independent cos/sin/sqrt evaluations of a hit interleave.
-template <bool kGeneral>
+template <bool kGeneral, bool kPosed>
 __global__ __launch_bounds__(kBlock) void light_samples_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
                                                                const int level) {
     const SceneView sc = view_of(scene_blob);
@@ -650,8 +652,9 @@ __global__ __launch_bounds__(kBlock) void light_samples_kernel(const uint8_t* __
     for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (threadIdx.x >= n) return;
         const uint32_t e = first + threadIdx.x;
-        const float4 hp = ws.q_p[par][e];
-        emit_light_samples<kGeneral>(sc, ws, e, mk(hp.x, hp.y, hp.z), __float_as_int(ws.q_d[par][e].w), S, my_rng);
+        const float4 hp = ws.q_p[par][e], hn = ws.q_n[par][e];
+        emit_light_samples<kGeneral, kPosed>(sc, ws, e, mk(hp.x, hp.y, hp.z), mk(hn.x, hn.y, hn.z), __float_as_int(ws.q_d[par][e].w), S,
+                                             my_rng);
     });
 }
 
@@ -693,8 +696,12 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
             V3 N = mk(hn.x, hn.y, hn.z);
             if (mode == SHADOW_HARD) N = normalize(N);
             V3 target = lpos;
-            if (mode == SHADOW_SOFT) target = ld3(ws.targets + (static_cast<size_t>(e) * S + j) * 3);
-            visible = !in_shadow_inline(sc, P, N, target);
+            if (mode == SHADOW_SOFT) {  // the first pass was done once for the hit's whole bundle of rays
+                target = ld3(ws.targets + (static_cast<size_t>(e) * S + j) * 3);
+                visible = !in_shadow_masked(sc, P, N, target, ws.cand[e]);
+            } else {
+                visible = !in_shadow_inline(sc, P, N, target);
+            }
         }
         if (pow2) {
             const unsigned long long m = __ballot(visible);
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
             if (next_hit) {
                 const uint32_t ne = s_out_base + static_cast<uint32_t>(rank);
                 push_entry(ws, par ^ 1, ne, nray, nhit, root, depth + 1);
-                if (samples) write_light_samples(scg, ws, ne, nhit.p, S, rng);
+                if (samples) write_light_samples<kView != kViewLdsUnposed>(scg, ws, ne, nhit.p, nhit.n, S, rng);
             }
             __syncthreads();
         }
@@ -1103,7 +1110,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
     const size_t A = c.ao_enabled && c.ao_samples > 0 ? static_cast<size_t>(c.ao_samples) : 0;
     const size_t rays = S > A ? S : A;  // light samples and AO directions share one array
-    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
+    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + (S ? 8 : 0) + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
     size_t rows = budget_bytes / (per_entry * (row_samples ? row_samples : 1));
     if (rows < 1) rows = 1;
     if (rows > static_cast<size_t>(p.shard.owned_rows)) rows = p.shard.owned_rows > 0 ? p.shard.owned_rows : 1;
@@ -1118,6 +1125,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
     w.queue_each = cap * 16;
     w.targets = cap * 12 * rays;
+    w.cand = S ? cap * 8 : 0;
     w.lit = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
     w.root_sample = cap * 4;
@@ -1140,10 +1148,11 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
     const int grid = general ? 256 : tuned_grid;
     for (int L = 0; L < levels; ++L) {
         if (soft && L == 0) {  // deeper levels: `shade` emits the samples of the entries it appends
+            constexpr bool posed = kView != kViewLdsUnposed;
             if (general)
-                hipLaunchKernelGGL(light_samples_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
+                hipLaunchKernelGGL((light_samples_kernel<true, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
             else
-                hipLaunchKernelGGL(light_samples_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
+                hipLaunchKernelGGL((light_samples_kernel<false, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
         }
         hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
         if (L == 0 && c.ao_enabled && c.ao_samples > 0 && !general) {

@@ -653,7 +653,14 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
 template <class SV>
 DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
     const RayQ q = prepare(r);
+#if defined(MCRT_ABL_NO_PHASE1)   // instruction-count ablations only (results are wrong)
+    unsigned long long cand = (1ull << (sc.n_meshes < 64 ? sc.n_meshes : 63)) - 1ull;
+#else
     unsigned long long cand = scene_candidates(sc, q, ~0ull, limit);
+#endif
+#if defined(MCRT_ABL_NO_PHASE2)
+    return cand == 0x123456789abcull;
+#endif
     while (cand) {
         const int i = __builtin_ctzll(cand);
         cand &= cand - 1ull;
@@ -668,6 +675,92 @@ DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
     }
     return false;
 }
+// The same with the first pass already done for this ray (a per-hit conservative candidate mask):
+// only the exact second pass runs.  Scenes beyond 64 meshes still scan their tail exactly.
+template <class SV>
+DEV bool any_hit_masked(const SV& sc, const Ray& r, float limit, unsigned long long cand) {
+    const RayQ q = prepare(r);
+    while (cand) {
+        const int i = __builtin_ctzll(cand);
+        cand &= cand - 1ull;
+        Cand c;
+        if (mesh_candidate(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
+    }
+    if constexpr (!SV::kLds) {
+        for (int i = 64; i < sc.n_meshes; ++i) {
+            Cand c;
+            if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
+        }
+    }
+    return false;
+}
+
+// Conservative first pass for ALL shadow rays of one hit towards a disk light (computeSoftShadow,
+// shading.cpp:28-60): origin O, light centre L, sample radius R.  Ray i runs from O to T_i with
+// |T_i - L| <= R, so its point at fraction s of the way lies within s·R of the central segment's
+// point O + s·(L - O).  If ray i meets a box B (fraction s <= far(B) / |T_i - O|, far = distance from
+// O to B's farthest corner), the central segment's point at the SAME fraction s lies in B inflated
+// by s·R.  The test below solves "exists s in [0,1] with O + s·(L-O) in B inflated by s·R" exactly
+// (linear in s per axis) with generous float slack; it only ever adds candidates — the exact
+// per-ray test (any_hit_masked) decides.  Posed meshes: their bounding sphere, inflated by R times
+// the largest fraction at which the sphere can be reached.
+template <bool kPosed, class SV>
+DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
+    const V3 D = L - O;
+    const float dd = dot(D, D);
+    const float Rb = R * 1.001f + 1e-6f;
+    const float dist_min = __builtin_sqrtf(dd) - Rb;  // the shortest ray of the bundle
+    const float inv_dist = dist_min > 1e-3f ? __builtin_amdgcn_rcpf(dist_min) * 1.001f : 3.0e38f;
+    const float slack = 2e-3f;
+    unsigned long long cand = 0ull;
+    const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
+    const unsigned long long roots = sc.roots;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        if (!((roots >> i) & 1ull)) continue;
+        const MeshData m = mesh_uniform(sc, i);
+        if (m.flags & MESH_EMPTY) continue;
+        bool pass;
+        if (kPosed && (m.flags & MESH_ROTATED)) {
+            pass = true;
+            if (!(m.radius < 0.0f)) {
+                const V3 oc = m.centre - O;
+                const float far = __builtin_sqrtf(dot(oc, oc)) + m.radius;
+                const float frac = smin(1.0f, far * inv_dist);
+                const float rr = m.radius + Rb * frac + slack;
+                float s = dd > 1e-12f ? dot(oc, D) * __builtin_amdgcn_rcpf(dd) : 0.0f;
+                s = sclamp(s, 0.0f, 1.0f);
+                const V3 q = oc - D * s;
+                pass = !(dot(q, q) > rr * rr * 1.001f);
+            }
+        } else {
+            // C(s) = O + s·D inside the box inflated by s·Rb (+ slack), for some s in [0, 1]: per axis
+            //   (D + Rb)·s >= lo - slack - o      and      (D - Rb)·s <= hi + slack - o
+            // — linear in s, so the feasible s form an interval
+            float s_in = -1e-4f, s_out = 1.0f + 1e-4f;
+            bool ok = true;
+            auto axis = [&](float o, float d, float l, float h) __attribute__((always_inline)) {
+                const float al = d + Rb, bl = l - slack - o;  // al·s >= bl
+                const float ah = d - Rb, bh = h + slack - o;  // ah·s <= bh
+                const float ql = bl * __builtin_amdgcn_rcpf(al), qh = bh * __builtin_amdgcn_rcpf(ah);
+                const bool flat_l = __builtin_fabsf(al) < 1e-6f, flat_h = __builtin_fabsf(ah) < 1e-6f;
+                // flat: the inequality does not depend on s (holds iff 0 >= bl resp. 0 <= bh; tiny margin)
+                ok = ok & !(flat_l & (bl > 1e-5f)) & !(flat_h & (bh < -1e-5f));
+                s_in = (!flat_l & (al > 0.0f)) ? smax(s_in, ql - 1e-5f) : s_in;
+                s_out = (!flat_l & (al < 0.0f)) ? smin(s_out, ql + 1e-5f) : s_out;
+                s_out = (!flat_h & (ah > 0.0f)) ? smin(s_out, qh + 1e-5f) : s_out;
+                s_in = (!flat_h & (ah < 0.0f)) ? smax(s_in, qh - 1e-5f) : s_in;
+            };
+            axis(O.x, D.x, m.lo.x, m.hi.x);
+            axis(O.y, D.y, m.lo.y, m.hi.y);
+            axis(O.z, D.z, m.lo.z, m.hi.z);
+            pass = ok & !(s_in > s_out);
+        }
+        if (pass) cand |= m.group;
+    }
+    return cand;
+}
+
 // shared copy for the rare sequential paths (AO, very long shadow streams, probes)
 DEVCALL bool any_hit_call(SceneView sc, Ray r, float limit) { return any_hit_inline(sc, r, limit); }
 template <class SV>
@@ -738,6 +831,17 @@ DEV bool in_shadow_inline(const SV& sc, V3 point, V3 normal, V3 light) {
     if (dist < 1e-6f) return false;
     Ray r{origin, vdiv(to, dist)};
     return any_hit_inline(sc, r, dist);
+}
+
+// isInShadow for one of the S rays of a hit whose bundle mask is known
+template <class SV>
+DEV bool in_shadow_masked(const SV& sc, V3 point, V3 normal, V3 light, unsigned long long cand) {
+    V3 origin = point + normal * 1e-3f;
+    V3 to = light - origin;
+    float dist = length(to);
+    if (dist < 1e-6f) return false;
+    Ray r{origin, vdiv(to, dist)};
+    return any_hit_masked(sc, r, dist, cand);
 }
 
 // computeSoftShadow :28-60, sequential form (probes; the trace kernel spreads the samples over lanes)
