@@ -823,6 +823,7 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
                                                        const int level) {
     __shared__ int s_wcnt[kBlock / 64];
     __shared__ uint32_t s_out_base;
+    __shared__ float4 s_np[kBlock], s_nn[kBlock];  // new hits (point + depth, normal) handed to the packed threads
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
@@ -902,19 +903,23 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
         int total = 0;
         const int rank = block_rank(next_hit, s_wcnt, total);
         if (total > 0) {  // uniform
-            // the append atomics of a level all hit one address and serialise (~11 ns each): issue
-            // it first and hide its queueing behind the seeding chain of the new entries' samples
-            uint32_t base = 0;
-            if (threadIdx.x == 0) base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
-            typename SampleRng<kGeneral>::type rng;
-            const bool samples = next_hit && mode == SHADOW_SOFT;
-            if (samples) seed_light_rng<kGeneral>(rng, nhit.p, depth + 1, S, my_rng);
-            if (threadIdx.x == 0) s_out_base = base;
+            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
+            const bool soft = mode == SHADOW_SOFT;
+            if (next_hit && soft) {  // hand the new hit to thread `rank`: the survivors' work below runs packed
+                s_np[rank] = make_float4(nhit.p.x, nhit.p.y, nhit.p.z, __int_as_float(depth + 1));
+                s_nn[rank] = make_float4(nhit.n.x, nhit.n.y, nhit.n.z, 0.0f);
+            }
             __syncthreads();
-            if (next_hit) {
-                const uint32_t ne = s_out_base + static_cast<uint32_t>(rank);
-                push_entry(ws, par ^ 1, ne, nray, nhit, root, depth + 1);
-                if (samples) write_light_samples<kView != kViewLdsUnposed>(scg, ws, ne, nhit.p, nhit.n, S, rng);
+            if (next_hit) push_entry(ws, par ^ 1, s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, depth + 1);
+            // The new entries' light samples (397-step seeding chain + S samples) and bundle masks.  Only a
+            // few lanes per wave survive; done in place every wave would pay for the whole chain at ~10 %
+            // lane use.  Threads 0 .. total-1 do it instead, so the chain runs in ceil(total / 64) waves.
+            if (soft && static_cast<int>(threadIdx.x) < total) {
+                const float4 np = s_np[threadIdx.x], nn = s_nn[threadIdx.x];
+                typename SampleRng<kGeneral>::type rng;
+                const V3 P = mk(np.x, np.y, np.z);
+                seed_light_rng<kGeneral>(rng, P, __float_as_int(np.w), S, my_rng);
+                write_light_samples<kView != kViewLdsUnposed>(scg, ws, s_out_base + threadIdx.x, P, mk(nn.x, nn.y, nn.z), S, rng);
             }
             __syncthreads();
         }

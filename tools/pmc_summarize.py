@@ -10,10 +10,11 @@ from collections import defaultdict
 root = sys.argv[1]
 per_dispatch = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[2] == "--dispatches" else 0
 acc = defaultdict(lambda: defaultdict(list))
-rows = defaultdict(dict)  # (pass-independent) dispatch order index -> {counter: value}
+seen = defaultdict(lambda: defaultdict(list))  # dispatch order index -> counter -> one value per PASS that collected it
 names = {}
 for f in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True)):
     order = {}
+    in_file = defaultdict(dict)  # a dispatch has several rows per counter (one per XCD / SE): summed within the pass
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "?").split("(")[0]
@@ -22,8 +23,13 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection
             if d not in order:
                 order[d] = len(order)
             i = order[d]
-            rows[i][row["Counter_Name"]] = rows[i].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            in_file[i][row["Counter_Name"]] = in_file[i].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
             names[i] = k
+    for i, cs in in_file.items():
+        for c, v in cs.items():
+            seen[i][c].append(v)
+# a counter collected in two passes is averaged, not added
+rows = {i: {c: sum(v) / len(v) for c, v in cs.items()} for i, cs in seen.items()}
 if per_dispatch:
     cols = sorted({c for r in rows.values() for c in r})
     print("idx kernel " + " ".join(cols))
