@@ -742,10 +742,11 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
 // ao_dirs — lane per hit: tangent frame, mt19937(ao seed), the A cosine-weighted directions, stored
 // where the (now consumed) light samples of level 0 were; ao — lane per (hit, direction): any hit
 // closer than the radius, counted per hit into lit[1] (free until the level-1 shadows).
+template <bool kPosed>
 __global__ __launch_bounds__(kBlock) void ao_dirs_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    const SceneView sc = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
     const int A = p.cfg.ao_samples;
-    (void)scene_blob;
     for_each_entry_block(ws, 0, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (threadIdx.x >= n) return;
         const uint32_t e = first + threadIdx.x;
@@ -754,6 +755,8 @@ __global__ __launch_bounds__(kBlock) void ao_dirs_kernel(const uint8_t* __restri
         const V3 N = normalize(mk(hn.x, hn.y, hn.z));
         const V3 T = (__builtin_fabsf(N.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), N)) : normalize(cross(mk(0, 1, 0), N));
         const V3 B = cross(N, T);
+        // the meshes any of this hit's AO rays can meet (the level-0 shadow masks are consumed by now)
+        ws.cand[e] = ball_candidates<kPosed>(sc, P + N * 1e-3f, p.cfg.ao_radius);
         MtShort rng;
         rng.seed(ao_seed(P));
         float* dst = ws.targets + static_cast<size_t>(e) * 3 * A;
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uin
                 const V3 N = normalize(mk(hn.x, hn.y, hn.z));
                 const V3 dir = ld3(ws.targets + (static_cast<size_t>(e) * A + j) * 3);
                 const Ray r{mk(hp.x, hp.y, hp.z) + N * 1e-3f, dir};
-                occluded = any_hit_inline(sc, r, radius);
+                occluded = any_hit_masked(sc, r, radius, ws.cand[e]);
             }
             if (pow2) {
                 const unsigned long long m = __ballot(occluded);
@@ -1115,7 +1118,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
     const size_t A = c.ao_enabled && c.ao_samples > 0 ? static_cast<size_t>(c.ao_samples) : 0;
     const size_t rays = S > A ? S : A;  // light samples and AO directions share one array
-    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + (S ? 8 : 0) + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
+    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + (rays ? 8 : 0) + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
     size_t rows = budget_bytes / (per_entry * (row_samples ? row_samples : 1));
     if (rows < 1) rows = 1;
     if (rows > static_cast<size_t>(p.shard.owned_rows)) rows = p.shard.owned_rows > 0 ? p.shard.owned_rows : 1;
@@ -1130,7 +1133,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_b
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
     w.queue_each = cap * 16;
     w.targets = cap * 12 * rays;
-    w.cand = S ? cap * 8 : 0;
+    w.cand = rays ? cap * 8 : 0;
     w.lit = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
     w.root_sample = cap * 4;
@@ -1161,7 +1164,7 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         }
         hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
         if (L == 0 && c.ao_enabled && c.ao_samples > 0 && !general) {
-            hipLaunchKernelGGL(ao_dirs_kernel, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
+            hipLaunchKernelGGL(ao_dirs_kernel<kView != kViewLdsUnposed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
             hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
         }
         if (general)

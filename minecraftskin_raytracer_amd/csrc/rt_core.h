@@ -761,6 +761,37 @@ DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
     return cand;
 }
 
+// Conservative first pass for ALL ambient-occlusion rays of one hit (computeAO, raytracer.cpp:38-78):
+// they start at O and only count hits closer than `radius`, so only meshes whose box (bounding
+// sphere when posed) comes within `radius` of O can matter.
+template <bool kPosed, class SV>
+DEV unsigned long long ball_candidates(const SV& sc, V3 O, float radius) {
+    const float reach = radius * 1.001f + 2e-3f;
+    unsigned long long cand = 0ull;
+    const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
+    const unsigned long long roots = sc.roots;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        if (!((roots >> i) & 1ull)) continue;
+        const MeshData m = mesh_uniform(sc, i);
+        if (m.flags & MESH_EMPTY) continue;
+        bool pass;
+        if (kPosed && (m.flags & MESH_ROTATED)) {
+            const V3 oc = m.centre - O;
+            const float rr = m.radius + reach;
+            pass = (m.radius < 0.0f) | !(dot(oc, oc) > rr * rr * 1.001f);
+        } else {
+            // distance from O to the box, per axis
+            const float dx = smax(smax(m.lo.x - O.x, O.x - m.hi.x), 0.0f);
+            const float dy = smax(smax(m.lo.y - O.y, O.y - m.hi.y), 0.0f);
+            const float dz = smax(smax(m.lo.z - O.z, O.z - m.hi.z), 0.0f);
+            pass = !(dx * dx + dy * dy + dz * dz > reach * reach * 1.001f);
+        }
+        if (pass) cand |= m.group;
+    }
+    return cand;
+}
+
 // shared copy for the rare sequential paths (AO, very long shadow streams, probes)
 DEVCALL bool any_hit_call(SceneView sc, Ray r, float limit) { return any_hit_inline(sc, r, limit); }
 template <class SV>
