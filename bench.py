@@ -296,7 +296,7 @@ def main() -> None:
                 "traffic": traffic,
                 "kernel": "whole wavefront pipeline of one frame (dominant stage: shadow_kernel, see profiles/)",
                 "note": "algorithmic bytes = 16 B x output pixels per frame; the path is VALU/latency-bound by construction "
-                        "(DESIGN.md): VALU pipe 42 % busy over one frame's chain, 71 % with four frames in flight (profiles/r01_v5)",
+                        "(DESIGN.md): VALU issue (4-cycle cadence) 41 % of one frame's chain, 72 % with four frames in flight (profiles/r01_v6)",
             },
         }
         if check is not None:
