@@ -208,8 +208,10 @@ typedef struct mcrt_timings {
 int mcrt_last_timings(mcrt_timings* out);
 
 /* Kernel-only timing helper used by bench.py: enqueues `iters` renders of the given shard on
- * `stream` bracketed by hipEvents recorded on that same stream, synchronises, and returns the
- * average per-launch duration in ms of the whole render and of the dominant (trace) kernel. */
+ * `stream`, each bracketed by hipEvents recorded on that same stream and waited for, and returns
+ * the average duration in ms of one render's whole pipeline (seeding pre-pass, every lane and
+ * level, resolve).  Both outputs carry that figure (the second one used to time the single trace
+ * kernel of an earlier design and is kept for ABI stability). */
 int mcrt_time_render_device(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_first,
                             int tile_row_step, int out_layout, float* d_out_rgba, void* stream,
                             int iters, float* avg_render_ms, float* avg_trace_kernel_ms);

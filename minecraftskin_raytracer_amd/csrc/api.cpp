@@ -71,16 +71,6 @@ struct DeviceBuffer {
 
 bool valid_frame(const mcrt_config* c) { return c->width > 0 && c->height > 0 && c->tile_size > 0; }
 
-// work units the trace kernel aims for (tuning knob: MCRT_TARGET_UNITS)
-int target_units() {
-    static const int v = [] {
-        const char* e = std::getenv("MCRT_TARGET_UNITS");
-        int n = e ? std::atoi(e) : 0;
-        return n > 0 ? n : 8192;
-    }();
-    return v;
-}
-
 int draws_per_sample(const mcrt_config& c) {
     int spp = c.samples_per_pixel > 1 ? c.samples_per_pixel : 1;
     return (spp > 1 ? 2 : 0) + ((c.dof_enabled && c.aperture > 1e-6f) ? 2 : 0);
@@ -188,7 +178,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     WorkspaceBytes w{};
     for (;;) {
         if (!sc->budget) sc->budget = workspace_budget();
-        w = plan_workspace(p, target_units(), sc->budget / static_cast<size_t>(n_lanes));
+        w = plan_workspace(p, sc->budget / static_cast<size_t>(n_lanes));
         hipError_t e = hipSuccess;
         auto want = [&](DeviceBuffer& b, size_t bytes) {
             if (e == hipSuccess) e = b.reserve(bytes);
@@ -254,11 +244,11 @@ int launch_lanes(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t 
         for (int li = 1; li < n_lanes; ++li) {
             Lane& ln = s->lanes[li];
             HIP_TRY(hipStreamWaitEvent(ln.stream, s->fork, 0));
-            HIP_TRY(launch_render(p[li], ln.stream, nullptr, nullptr));
+            HIP_TRY(launch_render(p[li], ln.stream));
             HIP_TRY(hipEventRecord(ln.done, ln.stream));
         }
     }
-    HIP_TRY(launch_render(p[0], stream, nullptr, nullptr));
+    HIP_TRY(launch_render(p[0], stream));
     for (int li = 1; li < n_lanes; ++li) HIP_TRY(hipStreamWaitEvent(stream, s->lanes[li].done, 0));
     return MCRT_OK;
 }

@@ -73,15 +73,14 @@ Shard make_shard(const mcrt_config& cfg, int first, int step);
 struct WorkspaceBytes {
     size_t tile_rng, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, root_sample, counters, hit_rng;
 };
-WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_bytes);
+WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes);
 constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
 constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
 constexpr int kCounterWords = 4096;
 
-// enqueue the whole pipeline: tile-RNG seeding (if needed), then per batch of tile rows
-// primary → [mt_draws, shadow, shade] per level → resolve.  If ev_k0/ev_k1 are non-null they are
-// recorded on `stream` around everything after the seeding pre-pass.
-hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t ev_k0, hipEvent_t ev_k1);
+// enqueue the whole pipeline of one lane on `stream`: tile-RNG seeding (if needed), then per batch of
+// tile rows plan → primary → [light_samples, shadow, (ao_dirs, ao,) shade] per level → resolve
+hipError_t launch_render(const RenderParams& p, hipStream_t stream);
 
 hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const float* packed, float* frame,
                               hipStream_t stream);

@@ -38,7 +38,6 @@ using namespace rt;
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 256;        // work items per chunk: one per thread
-constexpr int kMaxDrawsPerItem = 4;
 constexpr int kJitFloats = 4096;   // LDS floats for one pass of tile-stream draws
 constexpr int kPrimaryGrid = 1024; // persistent primary workgroups (4 per CU)
 constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
@@ -1104,11 +1103,10 @@ static int choose_parts_per_tile(const mcrt_config& cfg) {
     return static_cast<int>(parts);
 }
 
-WorkspaceBytes plan_workspace(RenderParams& p, int target_units, size_t budget_bytes) {
+WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes) {
     WorkspaceBytes w{};
     const mcrt_config& c = p.cfg;
     const int n_tiles = owned_tiles(p);
-    (void)target_units;
     p.parts_per_tile = choose_parts_per_tile(c);
     p.ws.stack_stride = c.max_bounces > 1 ? c.max_bounces : 1;
     const size_t spp = c.samples_per_pixel > 1 ? c.samples_per_pixel : 1;
@@ -1174,11 +1172,10 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
     }
 }
 
-hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t ev_k0, hipEvent_t ev_k1) {
+hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
     const int n = owned_tiles(p);
     if (n <= 0) return hipSuccess;
     if (p.draws_per_sample > 0) hipLaunchKernelGGL(seed_tiles_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
-    if (ev_k0) (void)hipEventRecord(ev_k0, stream);
     const size_t dyn = p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_face_entries / 6) * kMeshTabWords * 4 +
                                             static_cast<size_t>(p.lds_alpha_words) * 4
                                       : 0;
@@ -1205,7 +1202,6 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, hipEvent_t e
         const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
         hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, out, out8, p);
     }
-    if (ev_k1) (void)hipEventRecord(ev_k1, stream);
     return hipGetLastError();
 }
 

@@ -284,3 +284,38 @@ def test_render_survives_a_nearly_full_device(mcrt, gpu):
     finally:
         del hog
         torch.cuda.empty_cache()
+
+
+def test_recorded_launches_replay_the_same_frame(mcrt, gpu, oracle):
+    """A render's launches are issued directly the first time a parameter set is seen, recorded as a
+    graph the second time and replayed afterwards; more parameter sets than record slots evict each
+    other.  Every repetition must give the same bits."""
+    import torch
+
+    sd = scenes.skin_scene("S64", 6)
+    ds = mcrt.DeviceScene(sd)
+    st = torch.cuda.Stream()
+    cfgs = [abi.Config(width=96 + 8 * i, height=64, maxBounces=2, samplesPerPixel=2, tileSize=16) for i in range(6)]
+    want = [oracle.render(sd.ptr, c) for c in cfgs]
+    outs = [torch.zeros((c.height, c.width, 4), dtype=torch.float32, device="cuda") for c in cfgs]
+    for rep in range(4):  # 6 parameter sets cycle through 4 slots: every render of a set is a first or second sighting
+        for c, o in zip(cfgs, outs):
+            o.zero_()
+            ds.render_device(c, o.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
+        torch.cuda.synchronize()
+        for c, o, w in zip(cfgs, outs, want):
+            scenes.assert_bit_equal(o.cpu().numpy(), w, f"cycle {rep}, width {c.width}")
+    for rep in range(5):  # one set repeated: direct, recorded, replayed x3 — into alternating buffers
+        a = torch.zeros_like(outs[0])
+        ds.render_device(cfgs[0], a.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
+        ds.render_device(cfgs[0], outs[0].data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
+        torch.cuda.synchronize()
+        scenes.assert_bit_equal(a.cpu().numpy(), want[0], f"repeat {rep} (fresh buffer)")
+        scenes.assert_bit_equal(outs[0].cpu().numpy(), want[0], f"repeat {rep}")
+    ds.set_lanes(3)  # forced lanes go through the same recording
+    for rep in range(3):
+        outs[1].zero_()
+        ds.render_device(cfgs[1], outs[1].data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
+        torch.cuda.synchronize()
+        scenes.assert_bit_equal(outs[1].cpu().numpy(), want[1], f"3 lanes, repeat {rep}")
+    ds.close()
