@@ -200,7 +200,7 @@ def main() -> None:
 
     # priming (not part of W or K): every slot's first renders allocate its workspace and record its
     # launch graph; one-time costs, like the extension build
-    for k in range(3 * F):
+    for k in range(5 * F):  # launch recording happens at a parameter set's 4th render
         step(k)
     drain()
     sync()
@@ -309,6 +309,7 @@ def main() -> None:
         print(json.dumps(line), flush=True)
 
     for sc_ in scenes_:
+        sc_.check()  # raises if the device flagged an internal inconsistency during any render
         sc_.close()
     if world > 1:
         dist.destroy_process_group()

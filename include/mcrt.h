@@ -154,6 +154,17 @@ void mcrt_scene_destroy(mcrt_scene* scene);
 int mcrt_render_device(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_first,
                        int tile_row_step, int out_layout, float* d_out_rgba, void* stream);
 
+/* mcrt_scene_destroy keeps the scene's device workspace (up to MCRT_POOL_MB, default 8192 MiB; one
+ * idle set per device) for the next mcrt_scene_create / one-shot render on that device, because
+ * allocating it dominates a single small render.  mcrt_trim() frees what is being kept. */
+void mcrt_trim(void);
+
+/* Waits for the scene's device work and reports an internal inconsistency of the last renders (the
+ * workspace is sized for the tiles the host expects meshes to touch; the device flags a tile beyond
+ * that bound instead of writing past it).  MCRT_OK in every correct run; the one-shot entry points
+ * call it themselves. */
+int mcrt_scene_check(mcrt_scene* scene);
+
 /* A render is spread over internal *lanes* (streams with their own workspace, every n-th tile row of
  * the shard each, forked from / joined to the caller's stream) when the shard is large enough.
  * lanes = 0 restores that automatic choice, lanes >= 1 forces a count (at most 4).  A caller that

@@ -17,11 +17,12 @@ from .api import (  # noqa: F401
     quantize_rgba8,
     quantize_rgba8_device,
     render_png,
+    trim,
     unpack_rows_device,
 )
 
 __all__ = [
     "Config", "Mesh", "Scene", "Texture", "synthetic_skin", "DeviceScene", "MeshBuilder", "SceneDesc",
     "TileRenderer", "device_count", "flatten", "getBuiltinPoses", "probe_detmath", "probe_detmath_range",
-    "probe_mt_uniform", "quantize_rgba8", "quantize_rgba8_device", "unpack_rows_device", "ImageWriter", "render_png", "assemble_frame_device",
+    "probe_mt_uniform", "quantize_rgba8", "quantize_rgba8_device", "unpack_rows_device", "ImageWriter", "render_png", "assemble_frame_device", "trim",
 ]

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "mcrt_scene_desc_free", "mcrt_scene_flatten", "mcrt_probe_intersect", "mcrt_probe_trace",
     "mcrt_probe_mt_uniform", "mcrt_probe_detmath", "mcrt_probe_detmath_range",
     "mcrt_render_device_ex", "mcrt_write_png_rgba8", "mcrt_encode_png_rgba8", "mcrt_write_png_f32", "mcrt_render_png",
-    "mcrt_assemble_frame_device", "mcrt_scene_set_lanes",
+    "mcrt_assemble_frame_device", "mcrt_scene_set_lanes", "mcrt_trim", "mcrt_scene_check",
 ]
 
 
@@ -60,6 +60,8 @@ def load():
         "mcrt_render_png": (C.c_int, [desc_p, cfg_p, C.c_char_p, C.c_int]),
         "mcrt_assemble_frame_device": (C.c_int, [cfg_p, C.c_int, vp, C.c_size_t, vp, vp]),
         "mcrt_scene_set_lanes": (C.c_int, [vp, C.c_int]),
+        "mcrt_trim": (None, []),
+        "mcrt_scene_check": (C.c_int, [vp]),
         "mcrt_unpack_rows_device": (C.c_int, [cfg_p, C.c_int, C.c_int, vp, vp, vp]),
         "mcrt_quantize_rgba8_device": (C.c_int, [vp, vp, C.c_size_t, vp]),
         "mcrt_quantize_rgba8": (None, [f_p, u8_p, C.c_size_t]),

@@ -19,6 +19,11 @@ from .abi import Config, Mesh, Scene, SceneDescHolder, Texture
 Image = np.ndarray  # (H, W, 4) float32 — skin/image.h:9-15
 
 
+def trim() -> None:
+    """Free the device workspace kept for reuse by destroyed scenes (mcrt_trim)."""
+    load().mcrt_trim()
+
+
 def device_count() -> int:
     return int(load().mcrt_device_count())
 
@@ -208,6 +213,10 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+    def check(self) -> None:
+        """Wait for the scene's device work; raises if the device flagged an internal inconsistency."""
+        check(load().mcrt_scene_check(self._h))
 
     def set_lanes(self, lanes: int) -> None:
         """0 = automatic split of a render over internal streams, n >= 1 = exactly n (mcrt_scene_set_lanes)."""

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -96,6 +97,7 @@ struct mcrt_scene {
     uint32_t alpha_words = 0;
     uint32_t n_meshes = 0;
     bool posed = false;  // any mesh with MESH_ROTATED
+    std::vector<uint8_t> host_meshes;  // host copy of FlatHeader + FlatMesh[] (screen bounds for workspace planning)
     DeviceBuffer blob;
     Lane lanes[kMaxLanes];
     int forced_lanes = 0;  // mcrt_scene_set_lanes: 0 = automatic
@@ -107,6 +109,7 @@ struct mcrt_scene {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         unsigned long long last_use = 0;
+        int sightings = 0;
     };
     static constexpr int kRecorded = 4;
     Recorded recorded[kRecorded];
@@ -152,6 +155,60 @@ int lane_count(const mcrt_scene* s, const mcrt_config& cfg, const Shard& sh) {
     return std::max(1, std::min(lanes, sh.owned_rows));
 }
 
+// Upper bound, per owned tile row of `sh`, of the tiles that plan_units can find touched by a mesh.
+// It repeats the device's test (mesh_touches_tile + the thin-lens dilation) in double precision
+// with several pixels of extra margin, so it can only over-count; anything unusual → every tile.
+void touched_tiles_per_row(const mcrt_scene* sc, const mcrt_config& cfg, const Shard& sh, std::vector<int>& out) {
+    out.assign(static_cast<size_t>(sh.owned_rows > 0 ? sh.owned_rows : 0), sh.tiles_x);
+    if (sh.owned_rows <= 0 || sc->host_meshes.size() < sizeof(FlatHeader)) return;
+    const FlatHeader* h = reinterpret_cast<const FlatHeader*>(sc->host_meshes.data());
+    const FlatMesh* fm = reinterpret_cast<const FlatMesh*>(sc->host_meshes.data() + h->mesh_offset);
+    const int n = static_cast<int>(h->n_meshes);
+    if (n == 0) {
+        std::fill(out.begin(), out.end(), 0);
+        return;
+    }
+    if (!h->cull_ok || n >= 64) return;
+    const double W = cfg.width, H = cfg.height, T = cfg.tile_size;
+    const double aspect = static_cast<double>(static_cast<float>(cfg.width) / static_cast<float>(cfg.height));
+    const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
+    const double half_h = h->cam_half_h, half_w = half_h * aspect;
+    std::vector<uint8_t> grid(static_cast<size_t>(sh.tiles_x) * sh.tiles_y, 0);
+    for (int i = 0; i < n; ++i) {
+        const FlatMesh& m = fm[i];
+        double u0 = m.screen[0], v0 = m.screen[1], u1 = m.screen[2], v1 = m.screen[3];
+        if (!(u0 <= u1) || !std::isfinite(u0 + u1 + v0 + v1)) return;  // no bound: touches every tile
+        if (dof) {
+            const double focus = cfg.focus_distance > 0.0f ? cfg.focus_distance : h->cam_focus_auto;
+            if (!(m.depth[0] > 0.0f) || !(focus > 0.0)) return;
+            const double f_lo = 1.0 / focus, f_hi = std::sqrt(1.0 + half_w * half_w + half_h * half_h) / focus;
+            const double z_hi = 1.0 / m.depth[0], z_lo = 1.0 / m.depth[1];
+            const double d = std::max(std::max(std::fabs(z_hi - f_lo), std::fabs(z_hi - f_hi)),
+                                      std::max(std::fabs(z_lo - f_lo), std::fabs(z_lo - f_hi)));
+            const double pad = (cfg.aperture * d / half_h * 1.02 + 1e-3) * 1.01 + 1e-4;
+            if (!(pad < 1e6)) return;
+            u0 -= pad, v0 -= pad, u1 += pad, v1 += pad;
+        }
+        // bound units → pixels: u = (2x/W - 1) * aspect, v = 1 - 2y/H; the device pads tiles by 2 px + 1e-3 (u) / 2e-3 (v)
+        const double pad_x = 6.0 + (1e-3 * aspect + 1e-3) * W / (2.0 * aspect) + 1e-3 * W;
+        const double pad_y = 6.0 + 2e-3 * H / 2.0 + 1e-3 * H;
+        const double xa = (u0 / aspect + 1.0) * W * 0.5 - pad_x, xb = (u1 / aspect + 1.0) * W * 0.5 + pad_x;
+        const double ya = (1.0 - v1) * H * 0.5 - pad_y, yb = (1.0 - v0) * H * 0.5 + pad_y;
+        if (!std::isfinite(xa + xb + ya + yb)) return;
+        if (xb < 0.0 || yb < 0.0 || xa >= W || ya >= H) continue;
+        const int tx0 = static_cast<int>(std::max(0.0, std::floor(xa / T))), tx1 = static_cast<int>(std::min<double>(sh.tiles_x - 1, std::floor(xb / T)));
+        const int ty0 = static_cast<int>(std::max(0.0, std::floor(ya / T))), ty1 = static_cast<int>(std::min<double>(sh.tiles_y - 1, std::floor(yb / T)));
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) grid[static_cast<size_t>(ty) * sh.tiles_x + tx] = 1;
+    }
+    for (int j = 0; j < sh.owned_rows; ++j) {
+        const int ty = sh.first + j * sh.step;
+        int c = 0;
+        for (int tx = 0; tx < sh.tiles_x; ++tx) c += grid[static_cast<size_t>(ty) * sh.tiles_x + tx];
+        out[static_cast<size_t>(j)] = c;
+    }
+}
+
 // fill RenderParams for lane `li` of `n_lanes` over the shard (first, step) + make sure its
 // workspace exists (allocation only when it has to grow)
 int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int first, int step, int layout, float* d_out,
@@ -176,9 +233,13 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     // allocations, a shared GPU) the budget is halved — down to one tile row per batch — and the
     // lane's buffers are re-planned, instead of failing the render.
     WorkspaceBytes w{};
+    std::vector<int> row_touched;
+    touched_tiles_per_row(sc, *cfg, p.shard, row_touched);
     for (;;) {
         if (!sc->budget) sc->budget = workspace_budget();
-        w = plan_workspace(p, sc->budget / static_cast<size_t>(n_lanes));
+        w = plan_workspace(p, sc->budget / static_cast<size_t>(n_lanes), row_touched.empty() ? nullptr : row_touched.data());
+        if (p.rows_per_batch <= 0 && p.shard.owned_rows > 0)
+            return fail(MCRT_ERR_INVALID, "one tile row holds more than 2^31 samples (width x tile size x samples per pixel)");
         hipError_t e = hipSuccess;
         auto want = [&](DeviceBuffer& b, size_t bytes) {
             if (e == hipSuccess) e = b.reserve(bytes);
@@ -196,7 +257,11 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         want(s->lit[1], w.lit);
         want(s->stack, w.stack);
         want(s->root_sample, w.root_sample);
-        want(s->counters, w.counters);
+        {
+            const void* before = s->counters.ptr;
+            want(s->counters, w.counters);
+            if (e == hipSuccess && s->counters.ptr != before) e = hipMemset(s->counters.ptr, 0, w.counters);  // incl. the sticky overflow word
+        }
         want(s->hit_rng, w.hit_rng);
         if (e == hipSuccess) break;
         (void)hipGetLastError();
@@ -268,7 +333,7 @@ bool graphs_enabled() {
 // and replayed with a single hipGraphLaunch whenever the same parameters come again: ~75 us of
 // launch calls per render become one.
 int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, uint8_t* d_out8,
-                   hipStream_t stream) {
+                   hipStream_t stream, bool may_record = true) {
     const Shard whole = make_shard(*cfg, first, step);
     if (whole.owned_rows <= 0) return MCRT_OK;
     const int n_lanes = lane_count(s, *cfg, whole);
@@ -284,7 +349,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
         }
     }
     if (n_lanes > 1 && !s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
-    if (!graphs_enabled()) return launch_lanes(s, p, n_lanes, stream);
+    if (!graphs_enabled() || !may_record) return launch_lanes(s, p, n_lanes, stream);
 
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
@@ -295,26 +360,29 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     for (auto& r : s->recorded)
         if (r.exec && r.n_lanes == n_lanes && std::memcmp(r.p, p, sizeof(RenderParams) * n_lanes) == 0) slot = &r;
     if (!slot) {
-        // a parameter set is recorded the second time it is seen; one-off renders launch directly
+        // Recording costs tens of milliseconds (capture + instantiation): a parameter set is recorded
+        // at its kRecordAt-th sighting, earlier renders launch directly.
+        constexpr int kRecordAt = 4;
         mcrt_scene::Recorded* victim = &s->recorded[0];
         for (auto& r : s->recorded) {
             if (!r.exec && r.n_lanes == n_lanes && std::memcmp(r.p, p, sizeof(RenderParams) * n_lanes) == 0) {
-                victim = &r;  // seen once before: record now
-                slot = victim;
+                slot = &r;
                 break;
             }
             if (r.last_use < victim->last_use) victim = &r;
         }
-        if (!slot) {  // first sighting: remember the parameters, launch directly
+        if (!slot) {  // first sighting: remember the parameters
             if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
             if (victim->graph) (void)hipGraphDestroy(victim->graph);
             victim->exec = nullptr;
             victim->graph = nullptr;
             victim->n_lanes = n_lanes;
+            victim->sightings = 0;
             std::memcpy(victim->p, p, sizeof p);
-            victim->last_use = s->use_clock;
-            return launch_lanes(s, p, n_lanes, stream);
+            slot = victim;
         }
+        slot->last_use = s->use_clock;
+        if (++slot->sightings < kRecordAt) return launch_lanes(s, p, n_lanes, stream);
         if (!s->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
         hipError_t e = hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
@@ -345,6 +413,50 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     return MCRT_OK;
 }
 
+}  // namespace
+
+namespace {
+void destroy_scene_now(mcrt_scene* s);
+
+size_t workspace_bytes(const mcrt_scene* s) {
+    size_t n = s->blob.bytes;
+    for (const Lane& ln : s->lanes) {
+        n += ln.tile_rng.bytes + ln.scol.bytes + ln.units.bytes + ln.unit_hits[0].bytes + ln.unit_hits[1].bytes + ln.tile_mask.bytes;
+        for (const auto& q : ln.queues) n += q.bytes;
+        n += ln.targets.bytes + ln.cand.bytes + ln.lit[0].bytes + ln.lit[1].bytes + ln.stack.bytes + ln.root_sample.bytes +
+             ln.counters.bytes + ln.hit_rng.bytes;
+    }
+    return n;
+}
+
+std::mutex g_pool_mutex;
+std::vector<mcrt_scene*> g_pool;  // idle scene shells, at most one per device
+
+// keeps `s` for reuse unless it is large (MCRT_POOL_MB, default 8192) or the device already has one
+bool pool_scene(mcrt_scene* s) {
+    static const size_t limit = [] {
+        const char* e = std::getenv("MCRT_POOL_MB");
+        long long mb = e ? std::atoll(e) : 8192;
+        return static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
+    }();
+    if (workspace_bytes(s) > limit) return false;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (mcrt_scene* q : g_pool)
+        if (q->device == s->device) return false;
+    g_pool.push_back(s);
+    return true;
+}
+// device < 0: any
+mcrt_scene* take_pooled_scene(int device) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (device < 0 || g_pool[i]->device == device) {
+            mcrt_scene* s = g_pool[i];
+            g_pool.erase(g_pool.begin() + static_cast<long>(i));
+            return s;
+        }
+    return nullptr;
+}
 }  // namespace
 
 extern "C" {
@@ -420,20 +532,30 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
     if (n <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(MCRT_ERR_NO_DEVICE, "device index out of range");
     HIP_TRY(hipSetDevice(device));
-    mcrt_scene* s = new mcrt_scene();
-    s->device = device;
+    mcrt_scene* s = take_pooled_scene(device);  // an idle shell with its workspace, or nullptr
+    if (!s) {
+        s = new mcrt_scene();
+        s->device = device;
+    }
+    s->forced_lanes = 0;
     s->alpha_words = reinterpret_cast<const FlatHeader*>(b.data())->alpha_words;
     s->n_meshes = reinterpret_cast<const FlatHeader*>(b.data())->n_meshes;
+    s->posed = false;
     {
         const FlatHeader* fh = reinterpret_cast<const FlatHeader*>(b.data());
         const FlatMesh* fm = reinterpret_cast<const FlatMesh*>(b.data() + fh->mesh_offset);
         for (uint32_t i = 0; i < fh->n_meshes; ++i) s->posed = s->posed || (fm[i].flags & MESH_ROTATED) != 0;
     }
+    {
+        const FlatHeader* fh = reinterpret_cast<const FlatHeader*>(b.data());
+        s->host_meshes.assign(b.begin(), b.begin() + fh->mesh_offset + sizeof(FlatMesh) * fh->n_meshes);
+    }
     hipError_t e = s->blob.reserve(b.size());
     if (e == hipSuccess) e = hipMemcpy(s->blob.ptr, b.data(), b.size(), hipMemcpyHostToDevice);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&s->ev[i]);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        if (!s->ev[i]) e = hipEventCreate(&s->ev[i]);
     if (e != hipSuccess) {
-        mcrt_scene_destroy(s);
+        destroy_scene_now(s);
         return hip_fail(e, "scene upload");
     }
     *out = s;
@@ -444,6 +566,25 @@ void mcrt_scene_destroy(mcrt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();  // renders of this scene may still be running on the caller's streams
+    // A modest workspace is kept for the next scene on this device (one idle shell per device): a fresh
+    // hipMalloc of the lanes' buffers costs milliseconds per render call of the one-shot API
+    // (TileRenderer::render), tens of GB for large frames take far longer.  mcrt_trim() lets go of it.
+    if (pool_scene(s)) return;
+    destroy_scene_now(s);
+}
+
+void mcrt_trim(void) {
+    for (;;) {
+        mcrt_scene* s = take_pooled_scene(-1);
+        if (!s) break;
+        (void)hipSetDevice(s->device);
+        destroy_scene_now(s);
+    }
+}
+
+namespace {
+void destroy_scene_now(mcrt_scene* s) {
+    if (!s) return;
     s->blob.release();  // the other buffers are released by their destructors below
     for (auto& ln : s->lanes) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
@@ -459,6 +600,20 @@ void mcrt_scene_destroy(mcrt_scene* s) {
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     delete s;
+}
+}  // namespace
+
+int mcrt_scene_check(mcrt_scene* s) {
+    if (!s) return fail(MCRT_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (Lane& ln : s->lanes) {
+        if (!ln.counters.ptr) continue;
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpy(&flag, static_cast<uint32_t*>(ln.counters.ptr) + (kCounterWords - 1), 4, hipMemcpyDeviceToHost));
+        if (flag) return fail(MCRT_ERR_HIP, "internal error: more tiles were touched than the workspace was planned for");
+    }
+    return MCRT_OK;
 }
 
 int mcrt_scene_set_lanes(mcrt_scene* s, int lanes) {
@@ -491,8 +646,16 @@ int mcrt_render_device_ex(mcrt_scene* s, const mcrt_config* cfg, int first, int 
     return enqueue_render(s, cfg, first, step, layout, d_out_f32, d_out_rgba8, static_cast<hipStream_t>(stream));
 }
 
+static int time_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, void* stream,
+                       int iters, float* avg_render_ms, float* avg_trace_kernel_ms, bool may_record);
+
 int mcrt_time_render_device(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out,
                             void* stream, int iters, float* avg_render_ms, float* avg_trace_kernel_ms) {
+    return time_render(s, cfg, first, step, layout, d_out, stream, iters, avg_render_ms, avg_trace_kernel_ms, true);
+}
+
+static int time_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, void* stream,
+                       int iters, float* avg_render_ms, float* avg_trace_kernel_ms, bool may_record) {
     if (!s || !cfg || !d_out || iters < 1) return fail(MCRT_ERR_INVALID, "bad argument");
     if (!valid_frame(cfg)) return fail(MCRT_ERR_INVALID, "empty frame");
     HIP_TRY(hipSetDevice(s->device));
@@ -501,7 +664,7 @@ int mcrt_time_render_device(mcrt_scene* s, const mcrt_config* cfg, int first, in
     for (int i = 0; i < iters; ++i) {
         // both figures bracket the whole pipeline of the frame (fork, every lane, join) on `stream`
         HIP_TRY(hipEventRecord(s->ev[0], st));
-        int rc = enqueue_render(s, cfg, first, step, layout, d_out, nullptr, st);
+        int rc = enqueue_render(s, cfg, first, step, layout, d_out, nullptr, st, may_record);
         if (rc != MCRT_OK) return rc;
         HIP_TRY(hipEventRecord(s->ev[3], st));
         HIP_TRY(hipEventSynchronize(s->ev[3]));
@@ -567,8 +730,9 @@ int mcrt_render(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_
         return hip_fail(e, "frame allocation");
     }
     float kernel_ms = 0.0f, render_ms = 0.0f;
-    rc = mcrt_time_render_device(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, static_cast<float*>(frame.ptr), nullptr, 1,
-                                 &render_ms, &kernel_ms);
+    rc = time_render(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, static_cast<float*>(frame.ptr), nullptr, 1, &render_ms, &kernel_ms,
+                     /*may_record=*/false);
+    if (rc == MCRT_OK) rc = mcrt_scene_check(s);
     double t2 = now_ms();
     if (rc == MCRT_OK) {
         e = hipMemcpy(out_rgba, frame.ptr, npix * 16, hipMemcpyDeviceToHost);
@@ -605,7 +769,8 @@ int mcrt_render_tile(const mcrt_scene_desc* desc, const mcrt_config* cfg, int ti
     std::vector<float> host(row_floats);
     hipError_t e = band.reserve(row_floats * 4);
     if (e == hipSuccess) {
-        rc = mcrt_render_device(s, cfg, row, all.tiles_y, MCRT_LAYOUT_PACKED, static_cast<float*>(band.ptr), nullptr);
+        rc = enqueue_render(s, cfg, row, all.tiles_y, MCRT_LAYOUT_PACKED, static_cast<float*>(band.ptr), nullptr, nullptr, /*may_record=*/false);
+        if (rc == MCRT_OK) rc = mcrt_scene_check(s);
         if (rc == MCRT_OK) e = hipMemcpy(host.data(), band.ptr, row_floats * 4, hipMemcpyDeviceToHost);
     }
     band.release();
@@ -766,7 +931,8 @@ int mcrt_render_png(const mcrt_scene_desc* desc, const mcrt_config* cfg, const c
     std::vector<uint8_t> host(npix * 4);
     hipError_t e = plane.reserve(npix * 4);
     if (e == hipSuccess) {
-        rc = mcrt_render_device_ex(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, nullptr, static_cast<uint8_t*>(plane.ptr), nullptr);
+        rc = enqueue_render(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, nullptr, static_cast<uint8_t*>(plane.ptr), nullptr, /*may_record=*/false);
+        if (rc == MCRT_OK) rc = mcrt_scene_check(s);
         if (rc == MCRT_OK) e = hipMemcpy(host.data(), plane.ptr, npix * 4, hipMemcpyDeviceToHost);
     }
     plane.release();

@@ -31,6 +31,8 @@ struct WaveSpace {
     uint32_t* unit_hits[2]; // per unit: live hit entries of the current / next level (ping-pong by level parity)
     unsigned long long* tile_mask;  // per owned tile: meshes whose screen bound touches it
     uint32_t unit_cap;      // capacity of `units`
+    uint32_t tile_cap;      // tiles of a batch that may be touched by meshes (host-side superset of the device's culling):
+                            // touched tile number k of a batch owns slots [k, k+1) * tile_size^2 * spp
     float4* q_o[2];         // hit queues, ping-pong by level parity: ray origin  (.w = root entry, bit-cast)
     float4* q_d[2];         //                                         ray direction (.w = depth, bit-cast)
     float4* q_p[2];         //                                         hit point
@@ -41,7 +43,8 @@ struct WaveSpace {
     uint32_t* lit[2];       // [cap] visible light samples of a level's hits (ping-pong by level parity)
     float4* stack;          // [cap][stack_stride] level colours of the chain rooted at level-0 entry r
     uint32_t* root_sample;  // [cap] scol slot of the sample that level-0 entry r belongs to
-    uint32_t* counters;     // [0] number of units in `units` (the only global atomic: one add per touched tile)
+    uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [last] touched-tile bound exceeded (never, by construction),
+                            // [8 + L] entries of level L >= 1
     uint32_t* hit_rng;      // general variant: per-thread 624-word mt19937 states (long streams)
     uint32_t cap;           // entry capacity (= samples of the largest batch)
     int stack_stride;       // max(1, maxBounces)
@@ -73,7 +76,8 @@ Shard make_shard(const mcrt_config& cfg, int first, int step);
 struct WorkspaceBytes {
     size_t tile_rng, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, root_sample, counters, hit_rng;
 };
-WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes);
+// row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
+WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);
 constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
 constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
 constexpr int kCounterWords = 4096;

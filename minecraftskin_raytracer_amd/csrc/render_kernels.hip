@@ -231,6 +231,9 @@ struct ViewSel<kViewHbm> {
 // ---------------------------------------------------------------------------------------------
 // counters[0]: number of planned units (one atomic add per touched tile, in plan_units)
 constexpr int kCntUnits = 0;
+constexpr int kCntTiles = 1;     // touched tiles of the batch so far
+constexpr int kCntOverflow = kCounterWords - 1;  // set if more tiles are touched than the host planned for (a bug: the host
+                                                 // bound is a superset); the per-batch memset leaves this word alone
 
 // Rank of this thread's item among the workgroup's flagged items, and their total: ballot per wave,
 // four wave counts through LDS.  Collective (two barriers: the counts are reusable right after).
@@ -308,9 +311,16 @@ __global__ __launch_bounds__(64) void plan_units_kernel(const uint8_t* __restric
     const uint32_t parts = static_cast<uint32_t>(p.parts_per_tile);
     const uint32_t per = (npix + parts - 1u) / parts;
     const uint32_t used = (npix + per - 1u) / per;
+    // the k-th touched tile of the batch owns slot range k: the workspace is sized for the tiles that can
+    // be touched (host-side superset), not for every sample of the batch
+    const uint32_t ord = atomicAdd(&ws.counters[kCntTiles], 1u);
+    if (ord >= ws.tile_cap) {  // cannot happen; keep memory safe and leave a mark if it ever does
+        ws.counters[kCntOverflow] = 1u;
+        ws.tile_mask[tile] = 0ull;
+        return;
+    }
     const uint32_t slot0 = atomicAdd(&ws.counters[kCntUnits], used);
-    // slot ranges are a fixed function of the tile: no atomics, capacity = the batch's samples
-    const uint32_t base = static_cast<uint32_t>(t) * static_cast<uint32_t>(cfg.tile_size) * static_cast<uint32_t>(cfg.tile_size) * spp;
+    const uint32_t base = ord * static_cast<uint32_t>(cfg.tile_size) * static_cast<uint32_t>(cfg.tile_size) * spp;
     for (uint32_t i = 0; i < used; ++i) {
         const uint32_t a = i * per, b = min(npix, a + per);
         ws.units[slot0 + i] = make_uint4(static_cast<uint32_t>(tile), a, b, base + a * spp);
@@ -1103,29 +1113,54 @@ static int choose_parts_per_tile(const mcrt_config& cfg) {
     return static_cast<int>(parts);
 }
 
-WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes) {
+WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched) {
     WorkspaceBytes w{};
     const mcrt_config& c = p.cfg;
     const int n_tiles = owned_tiles(p);
     p.parts_per_tile = choose_parts_per_tile(c);
     p.ws.stack_stride = c.max_bounces > 1 ? c.max_bounces : 1;
     const size_t spp = c.samples_per_pixel > 1 ? c.samples_per_pixel : 1;
-    // slots of one tile row: every tile owns tile_size^2 * spp slots, clipped edge tiles included
-    const size_t row_samples = static_cast<size_t>(c.tile_size) * c.tile_size * static_cast<size_t>(p.shard.tiles_x) * spp;
+    // every tile that meshes can touch owns tile_size^2 * spp slots (clipped edge tiles included)
+    const size_t tile_slots = static_cast<size_t>(c.tile_size) * c.tile_size * spp;
     const size_t S = soft_sampling(c) ? static_cast<size_t>(c.shadow_samples) : 0;
     // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
     const size_t A = c.ao_enabled && c.ao_samples > 0 ? static_cast<size_t>(c.ao_samples) : 0;
     const size_t rays = S > A ? S : A;  // light samples and AO directions share one array
     const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + (rays ? 8 : 0) + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
-    size_t rows = budget_bytes / (per_entry * (row_samples ? row_samples : 1));
-    if (rows < 1) rows = 1;
-    if (rows > static_cast<size_t>(p.shard.owned_rows)) rows = p.shard.owned_rows > 0 ? p.shard.owned_rows : 1;
-    p.rows_per_batch = static_cast<int>(rows);
-    const size_t cap = rows * row_samples;
+    const int owned = p.shard.owned_rows;
+    auto row_count = [&](int j) -> size_t { return row_touched ? static_cast<size_t>(row_touched[j]) : static_cast<size_t>(p.shard.tiles_x); };
+    // touched tiles of the fullest batch when the shard is cut into batches of R owned rows
+    auto fullest = [&](int R) -> size_t {
+        size_t mx = 0;
+        for (int r0 = 0; r0 < owned; r0 += R) {
+            size_t sum = 0;
+            for (int j = r0; j < owned && j < r0 + R; ++j) sum += row_count(j);
+            if (sum > mx) mx = sum;
+        }
+        return mx;
+    };
+    // slots are indexed with 32 bits (with room for the 3·S / stack multipliers done in size_t)
+    size_t tile_budget = budget_bytes / (per_entry * (tile_slots ? tile_slots : 1));
+    if (tile_slots && tile_budget > 0x7ffffff0ull / tile_slots) tile_budget = 0x7ffffff0ull / tile_slots;
+    int rows = owned > 0 ? owned : 1;
+    if (owned > 0 && fullest(rows) > tile_budget) {  // largest R whose fullest batch fits (fullest is monotone in R)
+        int lo = 1, hi = owned;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            if (fullest(mid) <= tile_budget) lo = mid; else hi = mid - 1;
+        }
+        rows = lo;  // a batch is never smaller than one tile row
+    }
+    size_t cap_tiles = owned > 0 ? fullest(rows) : 0;
+    if (cap_tiles < 1) cap_tiles = 1;
+    p.rows_per_batch = rows;
+    if (tile_slots == 0 || cap_tiles > 0x7ffffff0ull / tile_slots) p.rows_per_batch = 0;  // one tile row alone exceeds the slot range: refused by the caller
+    const size_t cap = cap_tiles * tile_slots;
     p.ws.cap = static_cast<uint32_t>(cap > 0xfffffff0ull ? 0xfffffff0ull : cap);
+    p.ws.tile_cap = static_cast<uint32_t>(cap_tiles);
     w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 : 0;
     w.scol = cap * 16;
-    p.ws.unit_cap = static_cast<uint32_t>(rows * p.shard.tiles_x * p.parts_per_tile);
+    p.ws.unit_cap = static_cast<uint32_t>(cap_tiles * static_cast<size_t>(p.parts_per_tile));
     w.units = static_cast<size_t>(p.ws.unit_cap) * 16;
     w.unit_hits = static_cast<size_t>(p.ws.unit_cap) * 4;
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
@@ -1185,7 +1220,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
         const int rows = p.rows_per_batch < p.shard.owned_rows - r0 ? p.rows_per_batch : p.shard.owned_rows - r0;
         const int tile_base = r0 * p.shard.tiles_x;
         const int batch_tiles = rows * p.shard.tiles_x;
-        hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords) * 4, stream);
+        hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 1) * 4, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(plan_units_kernel, dim3(batch_tiles), dim3(64), 0, stream, p.scene, p, tile_base, batch_tiles);
         const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;

@@ -268,20 +268,24 @@ def test_render_survives_a_nearly_full_device(mcrt, gpu):
     ds.render_device(cfg, ref.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st)
     torch.cuda.synchronize()
     ds.close()
+    mcrt.trim()  # the closed scene's workspace would otherwise be handed to the next scene as is
     free, _total = torch.cuda.mem_get_info()
-    leave = 600 << 20  # the unconstrained workspace of this frame is ~1.3 GB
+    leave = 100 << 20  # the unconstrained workspace of this frame is ~0.25 GB (sized for the tiles meshes can touch)
     hog = torch.empty(max(0, free - leave), dtype=torch.uint8, device="cuda")
     try:
         free2, _ = torch.cuda.mem_get_info()
-        assert free2 < (900 << 20)
+        assert free2 < (400 << 20)
         ds2 = mcrt.DeviceScene(sd)
         # the output frame is carved out of the hog so that it does not compete for the leftover
         frame = hog[: cfg.height * cfg.width * 16].view(torch.float32).view(cfg.height, cfg.width, 4)
         ds2.render_device(cfg, frame.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st)
         torch.cuda.synchronize()
+        ds2.check()
         assert torch.equal(frame, ref)
         ds2.close()
+        mcrt.trim()
     finally:
+        frame = None
         del hog
         torch.cuda.empty_cache()
 
@@ -298,14 +302,14 @@ def test_recorded_launches_replay_the_same_frame(mcrt, gpu, oracle):
     cfgs = [abi.Config(width=96 + 8 * i, height=64, maxBounces=2, samplesPerPixel=2, tileSize=16) for i in range(6)]
     want = [oracle.render(sd.ptr, c) for c in cfgs]
     outs = [torch.zeros((c.height, c.width, 4), dtype=torch.float32, device="cuda") for c in cfgs]
-    for rep in range(4):  # 6 parameter sets cycle through 4 slots: every render of a set is a first or second sighting
+    for rep in range(4):  # 6 parameter sets cycle through 4 slots and keep evicting each other
         for c, o in zip(cfgs, outs):
             o.zero_()
             ds.render_device(c, o.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
         torch.cuda.synchronize()
         for c, o, w in zip(cfgs, outs, want):
             scenes.assert_bit_equal(o.cpu().numpy(), w, f"cycle {rep}, width {c.width}")
-    for rep in range(5):  # one set repeated: direct, recorded, replayed x3 — into alternating buffers
+    for rep in range(5):  # two sets repeated 5 times: direct x3, recorded at the 4th sighting, replayed
         a = torch.zeros_like(outs[0])
         ds.render_device(cfgs[0], a.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
         ds.render_device(cfgs[0], outs[0].data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
@@ -319,3 +323,27 @@ def test_recorded_launches_replay_the_same_frame(mcrt, gpu, oracle):
         torch.cuda.synchronize()
         scenes.assert_bit_equal(outs[1].cpu().numpy(), want[1], f"3 lanes, repeat {rep}")
     ds.close()
+
+
+def test_workspace_is_reused_across_scenes_and_trim_frees_it(mcrt, gpu, oracle):
+    """A destroyed scene leaves its workspace for the next scene on the device (one-shot renders would
+    otherwise re-allocate it every call); results do not depend on whose workspace is used; trim() frees it."""
+    import torch
+
+    mcrt.trim()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cfg = abi.Config(width=1280, height=720, maxBounces=2, samplesPerPixel=4)
+    a = scenes.skin_scene("S64", 0)
+    img_a = mcrt.TileRenderer.render(a, cfg)  # creates, renders, destroys → workspace pooled
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 < free0 - (30 << 20)  # something is being kept
+    b = scenes.skin_scene("S32", 6)  # different scene (posed, other tables) on the same shell
+    img_b = mcrt.TileRenderer.render(b, cfg)
+    free2, _ = torch.cuda.mem_get_info()
+    assert abs(free2 - free1) < (64 << 20)  # no second workspace
+    scenes.assert_bit_equal(img_a, oracle.render(a.ptr, cfg), "first scene")
+    scenes.assert_bit_equal(img_b, oracle.render(b.ptr, cfg), "second scene on the pooled workspace")
+    mcrt.trim()
+    free3, _ = torch.cuda.mem_get_info()
+    assert free3 > free1 + (30 << 20)
