@@ -538,6 +538,7 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
         s->device = device;
     }
     s->forced_lanes = 0;
+    s->budget = 0;  // a budget halved under memory pressure is not inherited
     s->alpha_words = reinterpret_cast<const FlatHeader*>(b.data())->alpha_words;
     s->n_meshes = reinterpret_cast<const FlatHeader*>(b.data())->n_meshes;
     s->posed = false;
