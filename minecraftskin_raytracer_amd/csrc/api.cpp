@@ -89,7 +89,7 @@ struct Lane {
     hipStream_t stream = nullptr;  // owned; unused for lane 0
     hipEvent_t done = nullptr;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
-    DeviceBuffer tile_rng, scol, units, unit_hits[2], tile_mask, queues[10], targets, cand, lit[2], stack, root_sample, counters, hit_rng;
+    DeviceBuffer tile_rng, tile_draws, scol, units, unit_hits[2], tile_mask, queues[10], targets, cand, lit[2], stack, root_sample, counters, hit_rng;
 };
 
 struct mcrt_scene {
@@ -245,6 +245,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
             if (e == hipSuccess) e = b.reserve(bytes);
         };
         want(s->tile_rng, w.tile_rng);
+        want(s->tile_draws, w.tile_draws);
         want(s->scol, w.scol);
         want(s->units, w.units);
         want(s->tile_mask, w.tile_mask);
@@ -269,7 +270,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
             return hip_fail(e, "workspace allocation");
         // make room: this lane's partially grown buffers go, then try again with half the budget
         (void)hipDeviceSynchronize();
-        s->tile_rng.release(), s->scol.release(), s->units.release(), s->tile_mask.release();
+        s->tile_rng.release(), s->tile_draws.release(), s->scol.release(), s->units.release(), s->tile_mask.release();
         s->unit_hits[0].release(), s->unit_hits[1].release();
         for (auto& q : s->queues) q.release();
         s->targets.release(), s->cand.release(), s->lit[0].release(), s->lit[1].release(), s->stack.release();
@@ -278,6 +279,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     }
     p.tile_rng = w.tile_rng ? static_cast<uint32_t*>(s->tile_rng.ptr) : nullptr;
     WaveSpace& ws = p.ws;
+    ws.tile_draws = static_cast<float*>(s->tile_draws.ptr);
     ws.scol = static_cast<float4*>(s->scol.ptr);
     ws.units = static_cast<uint4*>(s->units.ptr);
     ws.tile_mask = static_cast<unsigned long long*>(s->tile_mask.ptr);
@@ -421,7 +423,7 @@ void destroy_scene_now(mcrt_scene* s);
 size_t workspace_bytes(const mcrt_scene* s) {
     size_t n = s->blob.bytes;
     for (const Lane& ln : s->lanes) {
-        n += ln.tile_rng.bytes + ln.scol.bytes + ln.units.bytes + ln.unit_hits[0].bytes + ln.unit_hits[1].bytes + ln.tile_mask.bytes;
+        n += ln.tile_rng.bytes + ln.tile_draws.bytes + ln.scol.bytes + ln.units.bytes + ln.unit_hits[0].bytes + ln.unit_hits[1].bytes + ln.tile_mask.bytes;
         for (const auto& q : ln.queues) n += q.bytes;
         n += ln.targets.bytes + ln.cand.bytes + ln.lit[0].bytes + ln.lit[1].bytes + ln.stack.bytes + ln.root_sample.bytes +
              ln.counters.bytes + ln.hit_rng.bytes;

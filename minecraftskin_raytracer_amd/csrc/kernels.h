@@ -30,6 +30,8 @@ struct WaveSpace {
     uint4* units;           // units of the tiles meshes can touch: {owned tile, first pixel, end pixel, slot base}
     uint32_t* unit_hits[2]; // per unit: live hit entries of the current / next level (ping-pong by level parity)
     unsigned long long* tile_mask;  // per owned tile: meshes whose screen bound touches it
+    float* tile_draws;      // [tiles of the batch][draws_stride] every draw of a tile's mt19937 stream, as uniform floats
+    uint32_t draws_stride;  // tile_size^2 * spp * draws_per_sample
     uint32_t unit_cap;      // capacity of `units`
     uint32_t tile_cap;      // tiles of a batch that may be touched by meshes (host-side superset of the device's culling):
                             // touched tile number k of a batch owns slots [k, k+1) * tile_size^2 * spp
@@ -74,7 +76,7 @@ Shard make_shard(const mcrt_config& cfg, int first, int step);
 // p.ws.cap / p.ws.stack_stride.  budget_bytes bounds the per-batch workspace (a batch is never
 // smaller than one tile row).
 struct WorkspaceBytes {
-    size_t tile_rng, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, root_sample, counters, hit_rng;
+    size_t tile_rng, tile_draws, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, root_sample, counters, hit_rng;
 };
 // row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
 WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);

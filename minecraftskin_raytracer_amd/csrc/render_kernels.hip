@@ -38,7 +38,6 @@ using namespace rt;
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 256;        // work items per chunk: one per thread
-constexpr int kJitFloats = 4096;   // LDS floats for one pass of tile-stream draws
 constexpr int kPrimaryGrid = 1024; // persistent primary workgroups (4 per CU)
 constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
 
@@ -82,56 +81,64 @@ __global__ __launch_bounds__(64) void seed_tiles_kernel(RenderParams p, int n_ti
 }
 
 // ---------------------------------------------------------------------------------------------
-// cooperative mt19937 block generation in LDS
+// tile_streams: every draw renderTile takes from a tile's mt19937 (tile_renderer.cpp:78-99: per pixel
+// in row-major order, per sample, 2 jitter draws if spp > 1, then 2 lens draws if DOF is on), as
+// uniform floats in HBM.  One WAVE per tile: the engine's twist runs inside the wave on a
+// ping-pong state in LDS — LDS operations of one wave are ordered, a wave barrier keeps the
+// compiler from moving them — so there is no workgroup barrier anywhere and all tiles of a batch
+// advance in parallel.  (Generating the stream inside `primary` with block-wide twists made that
+// kernel barrier-bound: 3 barriers per 624 draws, ~60 us of the 1080p / 4 spp frame, milliseconds
+// at 64 spp; units that start mid-tile also had to re-run the twists before their first draw.)
 // ---------------------------------------------------------------------------------------------
-struct TileStream {
-    uint32_t* st;  // 2 x 624 words ping-pong
-    int cur;       // which half holds the current block
-    int block;     // index of the block held (-1: seeded, nothing generated yet)
-};
-
-// one twist: st[cur] → st[cur^1]; all threads of the workgroup must call
-__device__ __forceinline__ void stream_twist(TileStream& ts) {
-    const uint32_t* o = ts.st + ts.cur * 624;
-    uint32_t* n = ts.st + (ts.cur ^ 1) * 624;
-    const int tid = threadIdx.x;
-    // phase A: k in [0,227) — old values only
-    if (tid < 227) n[tid] = mt_twist(o[tid], o[tid + 1], o[tid + 397]);
-    __syncthreads();
-    // phase B: k in [227,454) — needs new[k-227]
-    if (tid < 227) {
-        int k = tid + 227;
-        n[k] = mt_twist(o[k], o[k + 1], n[k - 227]);
+constexpr int kStreamWaves = 4;  // tiles per workgroup
+// executed by one wave; `st` = its 2 x 624 words of LDS; `t` = the tile's index within the batch
+__device__ __forceinline__ void tile_stream_wave(const uint32_t* __restrict__ tile_rng, float* __restrict__ tile_draws,
+                                                 const RenderParams& p, const TileGeom& tg, int tile, int t, uint32_t* st, int lane) {
+    const int spp = p.cfg.samples_per_pixel > 1 ? p.cfg.samples_per_pixel : 1;
+    const unsigned long long total = static_cast<unsigned long long>(tg.w) * tg.h * spp * p.draws_per_sample;
+    const uint32_t* src = tile_rng + static_cast<size_t>(tile) * 624;
+    for (int e = lane; e < 624; e += 64) st[e] = src[e];
+    auto wave_sync = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    wave_sync();
+    float* dst = tile_draws + static_cast<size_t>(t) * p.ws.draws_stride;
+    int cur = 0;
+    for (unsigned long long done = 0; done < total; done += 624) {
+        const uint32_t* o = st + cur * 624;
+        uint32_t* n = st + (cur ^ 1) * 624;
+        // mt19937 twist: new[k] from old[k], old[k+1] and old[k+397] (= new[k-227] once k >= 227); the
+        // loops are unrolled so that a phase's LDS reads are all in flight before its first write
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            if (k < 227) n[k] = mt_twist(o[k], o[k + 1], o[k + 397]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 227 + lane + 64 * i;
+            if (k < 454) n[k] = mt_twist(o[k], o[k + 1], n[k - 227]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = 454 + lane + 64 * i;
+            if (k < 624) n[k] = mt_twist(o[k], (k == 623) ? n[0] : o[k + 1], n[k - 227]);
+        }
+        wave_sync();
+        cur ^= 1;
+        const unsigned long long left = total - done;
+        const int m = left < 624ull ? static_cast<int>(left) : 624;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int e = lane + 64 * i;
+            if (e < m) dst[done + e] = mt_to_unit(mt_temper(n[e]));
+        }
     }
-    __syncthreads();
-    // phase C: k in [454,624) — new[k-227]; k = 623 wraps to new[0]
-    if (tid < 170) {
-        int k = tid + 454;
-        uint32_t nxt = (k == 623) ? n[0] : o[k + 1];
-        n[k] = mt_twist(o[k], nxt, n[k - 227]);
-    }
-    __syncthreads();
-    ts.cur ^= 1;
-    ts.block += 1;
 }
 
-// Fill jit[0 .. count) with `count` consecutive stream draws, starting at draw `off` of block
-// `blk`, as uniform floats.  Collective.  A work unit that starts in the middle of a tile's stream
-// catches up by twisting from the seeded state.
-__device__ __forceinline__ void stream_fill(TileStream& ts, float* jit, int blk, int off, int count) {
-    int out = 0;
-    while (count > 0) {
-        while (ts.block < blk) stream_twist(ts);
-        const uint32_t* s = ts.st + ts.cur * 624;
-        const int m = min(624 - off, count);
-        for (int e = threadIdx.x; e < m; e += kBlock) jit[out + e] = mt_to_unit(mt_temper(s[off + e]));
-        out += m;
-        count -= m;
-        off = 0;
-        ++blk;
-    }
-    __syncthreads();
-}
 // ---------------------------------------------------------------------------------------------
 // pixel store: the float4 frame and/or its RGBA8 quantisation `(u8)(clamp(c,0,1)*255+0.5)`
 // (image_writer.cpp:18-22 ≡ image.cpp:31-36) — the epilogue of `primary` (background tiles) and `resolve`
@@ -264,18 +271,12 @@ __device__ __forceinline__ void push_entry(const WaveSpace& ws, int parity, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// plan_units: one wave per tile of the batch
+// plan_tiles: one wave per tile of the batch — which meshes can touch the tile, its units and slot
+// range (plan_tile), then the tile's draws (tile_stream_wave)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void plan_units_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
-                                                        const int tile_base, const int n_tiles) {
-    const int t = blockIdx.x;
-    if (t >= n_tiles) return;
-    const SceneView sc = view_of(scene_blob);
+__device__ __forceinline__ void plan_tile(const SceneView& sc, const RenderParams& p, const TileGeom& tg, int tile, int lane) {
     const mcrt_config& cfg = p.cfg;
     const WaveSpace& ws = p.ws;
-    const int tile = tile_base + t;
-    const TileGeom tg = tile_of(p, tile);
-    const int lane = threadIdx.x;
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
     const bool cull = sc.hdr->cull_ok != 0 && sc.n_meshes < 64;
     const float aspect = static_cast<float>(cfg.width) / static_cast<float>(cfg.height);
@@ -327,37 +328,29 @@ __global__ __launch_bounds__(64) void plan_units_kernel(const uint8_t* __restric
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// primary: persistent workgroups; touched units first, then the background tiles
-// ---------------------------------------------------------------------------------------------
-// the tile's seeded mt19937 state into LDS and the stream position of the first draw
-__device__ __forceinline__ void stream_open(TileStream& ts, uint32_t* s_mt, const uint32_t* __restrict__ tile_rng, int tile,
-                                            unsigned long long first_draw, int& sblk, int& soff) {
-    ts.st = s_mt;
-    ts.cur = 0;
-    ts.block = -1;
-    const uint32_t* src = tile_rng + static_cast<size_t>(tile) * 624;
-    for (int e = threadIdx.x; e < 624; e += kBlock) s_mt[e] = src[e];
-    if (first_draw < 0xffffffffull) {
-        const uint32_t fd = static_cast<uint32_t>(first_draw);
-        sblk = static_cast<int>(fd / 624u);
-        soff = static_cast<int>(fd - static_cast<uint32_t>(sblk) * 624u);
-    } else {
-        sblk = static_cast<int>(first_draw / 624ull);
-        soff = static_cast<int>(first_draw - static_cast<unsigned long long>(sblk) * 624ull);
-    }
-    __syncthreads();
+__global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uint8_t* __restrict__ scene_blob,
+                                                                       const uint32_t* __restrict__ tile_rng,
+                                                                       float* __restrict__ tile_draws, const RenderParams p,
+                                                                       const int tile_base, const int n_tiles) {
+    __shared__ uint32_t s_state[kStreamWaves][2 * 624];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = static_cast<int>(blockIdx.x) * kStreamWaves + wave;
+    if (t >= n_tiles) return;  // wave-uniform; there is no workgroup barrier in this kernel
+    const int tile = tile_base + t;
+    const TileGeom tg = tile_of(p, tile);
+    plan_tile(view_of(scene_blob), p, tg, tile, lane);
+    if (p.draws_per_sample > 0) tile_stream_wave(tile_rng, tile_draws, p, tg, tile, t, s_state[wave], lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// primary: persistent workgroups; touched units first, then the background tiles.  A sample's draws
+// sit in tile_draws at ((pixel in tile) * spp + sample) * draws_per_sample.
+// ---------------------------------------------------------------------------------------------
 template <int kView>
 __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restrict__ scene_blob,
-                                                         const uint32_t* __restrict__ tile_rng,
+                                                         const float* __restrict__ tile_draws,
                                                          float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p,
                                                          const int tile_base, const int n_tiles) {
-    __shared__ uint32_t s_mt[2 * 624];
-    __shared__ float s_jit[kJitFloats];
-    __shared__ float4 s_col[kChunk];
-    __shared__ float4 s_carry[2];
     __shared__ int s_wcnt[kBlock / 64];
     extern __shared__ __align__(16) unsigned char s_dyn[];
 
@@ -375,11 +368,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
     if (focusDist <= 0.0f) focusDist = sc.hdr->cam_focus_auto;
     const float inv_spp = 1.0f / static_cast<float>(spp);
     const uint32_t n_units = ws.counters[kCntUnits];
-    TileStream ts;
-    ts.st = s_mt;
-    ts.cur = 0;
-    ts.block = -1;
-    int sblk = 0, soff = 0;
+    const size_t stride = ws.draws_stride;
 
     // ================= units of tiles that meshes can touch: thread per sample =================
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -389,38 +378,24 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
         const uint32_t slot_base = ud.w;
         const TileGeom tg = tile_of(p, tile);
         const unsigned long long mesh_mask = ws.tile_mask[tile];
-        __syncthreads();
-        if (dd > 0) stream_open(ts, s_mt, tile_rng, tile, static_cast<unsigned long long>(pp0) * spp * dd, sblk, soff);
+        const float* draws = tile_draws + static_cast<size_t>(tile - tile_base) * stride;
+        const unsigned n_samples = (pp1 - pp0) * static_cast<unsigned>(spp);
 
-        uint32_t unit_hits = 0;      // hits so far: they occupy slots slot_base .. slot_base + unit_hits
-        unsigned cp = pp0, cs = 0;   // chunk cursor: sample cs of pixel cp
-        while (cp < pp1) {
-            const unsigned pix_left = pp1 - cp;
-            int n = kChunk;
-            if (pix_left <= static_cast<unsigned>(kChunk)) {
-                const unsigned long long left = static_cast<unsigned long long>(pix_left) * spp - cs;
-                if (left < static_cast<unsigned long long>(kChunk)) n = static_cast<int>(left);
-            }
-            if (dd > 0) {
-                stream_fill(ts, s_jit, sblk, soff, n * dd);
-                soff += n * dd;
-                sblk += soff / 624;
-                soff %= 624;
-            }
+        uint32_t unit_hits = 0;  // hits so far: they occupy slots slot_base .. slot_base + unit_hits
+        for (unsigned s0 = 0; s0 < n_samples; s0 += kChunk) {  // uniform trip count
             bool is_hit = false;
             Ray ray{mk(0, 0, 0), mk(0, 0, 0)};
             Hit hit;
             hit.hit = false;
             uint32_t sample_slot = 0;
-            if (tid < n) {
-                const unsigned sidx = cs + tid;  // < spp + kChunk
-                const unsigned dpix = sidx / static_cast<unsigned>(spp);
-                const unsigned pix = cp + dpix;
+            const unsigned sidx = s0 + tid;  // sample of the unit, in stream order
+            if (sidx < n_samples) {
+                const unsigned pix = pp0 + sidx / static_cast<unsigned>(spp);
                 const unsigned uly = pix / static_cast<unsigned>(tg.w);
                 const int ly = static_cast<int>(uly);
                 const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
                 const int px = tg.x + lx, py = tg.y + ly;
-                const float* jd = s_jit + tid * dd;
+                const float* jd = draws + (static_cast<size_t>(pp0) * spp + sidx) * dd;
                 float jx = 0.5f, jy = 0.5f;
                 int dpos = 0;
                 if (spp > 1) {
@@ -430,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                 }
                 const float su = (static_cast<float>(px) + jx) / fW;
                 const float sv = (static_cast<float>(py) + jy) / fH;
-                sample_slot = slot_base + (pix - pp0) * static_cast<uint32_t>(spp) + (sidx - dpix * static_cast<unsigned>(spp));
+                sample_slot = slot_base + sidx;
                 ray = dof ? lens_ray(sc, su, sv, aspect, cfg.aperture, focusDist, jd[dpos], jd[dpos + 1])
                           : camera_ray(sc, su, sv, aspect);
                 hit = hit_scene(sc, ray, mesh_mask);
@@ -452,123 +427,40 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                 ws.root_sample[e] = sample_slot;
             }
             unit_hits += static_cast<uint32_t>(total);
-            const unsigned adv = cs + static_cast<unsigned>(n);
-            cp += adv / static_cast<unsigned>(spp);
-            cs = adv % static_cast<unsigned>(spp);
         }
         if (tid == 0) ws.unit_hits[0][u] = unit_hits;
     }
 
     // ================= background tiles: nothing can be hit, no ray is needed =================
-    // a whole 256-pixel pass of draws fits the LDS buffer → thread per pixel, no colour staging
-    const bool pixel_path = static_cast<long long>(kBlock) * spp * dd <= kJitFloats;
+    // thread per pixel, its samples in order as renderTile sums them (tile_renderer.cpp:116-124); no barriers
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int tile = tile_base + t;
         if (ws.tile_mask[tile] != 0ull) continue;  // uniform
         const TileGeom tg = tile_of(p, tile);
         const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
-        __syncthreads();
-        if (dd > 0) stream_open(ts, s_mt, tile_rng, tile, 0ull, sblk, soff);
-
-        if (pixel_path) {
-            for (unsigned q0 = 0; q0 < npix; q0 += kBlock) {
-                const int npx = static_cast<int>(min(static_cast<unsigned>(kBlock), npix - q0));
-                if (dd > 0) {
-                    stream_fill(ts, s_jit, sblk, soff, npx * spp * dd);
-                    soff += npx * spp * dd;
-                    sblk += soff / 624;
-                    soff %= 624;
-                }
-                if (tid < npx) {
-                    const unsigned pix = q0 + tid;
-                    const unsigned uly = pix / static_cast<unsigned>(tg.w);
-                    const int ly = static_cast<int>(uly);
-                    const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
-                    const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
-                    float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
-                    for (int s = 0; s < spp; ++s) {
-                        float jx = 0.5f, jy = 0.5f;
-                        if (spp > 1) {
-                            jx = s_jit[(tid * spp + s) * dd];
-                            jy = s_jit[(tid * spp + s) * dd + 1];
-                        }
-                        const C4 c = background(sc, cfg, (fx + jx) / fW, (fy + jy) / fH);  // tile_renderer.cpp:111-114
-                        ar += c.r;
-                        ag += c.g;
-                        ab += c.b;
-                        aa += c.a;
-                    }
-                    const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
-                    store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
-                                make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp));
-                }
-                if (dd > 0) __syncthreads();  // s_jit is refilled by the next pass
-            }
-            continue;
-        }
-
-        // long per-pixel streams: thread per sample, ordered accumulation through LDS
-        unsigned cp = 0, cs = 0;
-        int parity = 0;
-        while (cp < npix) {
-            const unsigned pix_left = npix - cp;
-            int n = kChunk;
-            if (pix_left <= static_cast<unsigned>(kChunk)) {
-                const unsigned long long left = static_cast<unsigned long long>(pix_left) * spp - cs;
-                if (left < static_cast<unsigned long long>(kChunk)) n = static_cast<int>(left);
-            }
-            if (dd > 0) {
-                stream_fill(ts, s_jit, sblk, soff, n * dd);
-                soff += n * dd;
-                sblk += soff / 624;
-                soff %= 624;
-            }
-            if (tid < n) {
-                const unsigned sidx = cs + tid;
-                const unsigned pix = cp + sidx / static_cast<unsigned>(spp);
-                const unsigned uly = pix / static_cast<unsigned>(tg.w);
-                const int ly = static_cast<int>(uly);
-                const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
+        const float* draws = tile_draws + static_cast<size_t>(t) * stride;
+        for (unsigned pix = tid; pix < npix; pix += kBlock) {
+            const unsigned uly = pix / static_cast<unsigned>(tg.w);
+            const int ly = static_cast<int>(uly);
+            const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
+            const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
+            const float* jd = draws + static_cast<size_t>(pix) * spp * dd;
+            float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
+            for (int sidx = 0; sidx < spp; ++sidx) {
                 float jx = 0.5f, jy = 0.5f;
                 if (spp > 1) {
-                    jx = s_jit[tid * dd];
-                    jy = s_jit[tid * dd + 1];
+                    jx = jd[sidx * dd];
+                    jy = jd[sidx * dd + 1];
                 }
-                const C4 c = background(sc, cfg, (static_cast<float>(tg.x + lx) + jx) / fW, (static_cast<float>(tg.y + ly) + jy) / fH);
-                s_col[tid] = make_float4(c.r, c.g, c.b, c.a);
+                const C4 c = background(sc, cfg, (fx + jx) / fW, (fy + jy) / fH);  // tile_renderer.cpp:111-114
+                ar += c.r;
+                ag += c.g;
+                ab += c.b;
+                aa += c.a;
             }
-            __syncthreads();
-            // pixel cp+i owns chunk items [i*spp - cs, (i+1)*spp - cs) clipped to [0, n)
-            const int n_pix = static_cast<int>((cs + n - 1) / static_cast<unsigned>(spp)) + 1;
-            for (int i = tid; i < n_pix; i += kBlock) {
-                const long long wb = static_cast<long long>(i) * spp - cs, we = wb + spp;
-                const int sb = wb > 0 ? static_cast<int>(wb) : 0;
-                const int se = we < n ? static_cast<int>(we) : n;
-                float4 acc = (wb >= 0) ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : s_carry[parity ^ 1];
-                for (int q = sb; q < se; ++q) {
-                    float4 sc4 = s_col[q];
-                    acc.x += sc4.x;
-                    acc.y += sc4.y;
-                    acc.z += sc4.z;
-                    acc.w += sc4.w;
-                }
-                if (we <= n) {
-                    const unsigned pix = cp + static_cast<unsigned>(i);
-                    const unsigned uly = pix / static_cast<unsigned>(tg.w);
-                    const int ly = static_cast<int>(uly);
-                    const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
-                    const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
-                    store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
-                                make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp));
-                } else {
-                    s_carry[parity] = acc;
-                }
-            }
-            __syncthreads();
-            const unsigned adv = cs + static_cast<unsigned>(n);
-            cp += adv / static_cast<unsigned>(spp);
-            cs = adv % static_cast<unsigned>(spp);
-            parity ^= 1;
+            const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
+            store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
+                        make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp));
         }
     }
 }
@@ -1139,26 +1031,38 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
         }
         return mx;
     };
+    // every tile of a batch (touched or not) also holds its jitter / lens draws: tile_size^2 * spp * draws floats
+    const size_t draws_stride = static_cast<size_t>(c.tile_size) * c.tile_size * spp * static_cast<size_t>(p.draws_per_sample);
+    const size_t draws_row_bytes = draws_stride * 4 * static_cast<size_t>(p.shard.tiles_x);
+    p.ws.draws_stride = static_cast<uint32_t>(draws_stride > 0xffffffffull ? 0xffffffffull : draws_stride);
     // slots are indexed with 32 bits (with room for the 3·S / stack multipliers done in size_t)
     size_t tile_budget = budget_bytes / (per_entry * (tile_slots ? tile_slots : 1));
     if (tile_slots && tile_budget > 0x7ffffff0ull / tile_slots) tile_budget = 0x7ffffff0ull / tile_slots;
     int rows = owned > 0 ? owned : 1;
-    if (owned > 0 && fullest(rows) > tile_budget) {  // largest R whose fullest batch fits (fullest is monotone in R)
+    // a batch of R rows fits when its hit workspace and its draws fit the budget together
+    auto fits = [&](int R) -> bool {
+        const size_t f = fullest(R);
+        if (f > tile_budget) return false;
+        return f * tile_slots * per_entry + static_cast<size_t>(R) * draws_row_bytes <= budget_bytes;
+    };
+    if (owned > 0 && !fits(rows)) {  // largest R that fits (monotone in R)
         int lo = 1, hi = owned;
         while (lo < hi) {
             const int mid = (lo + hi + 1) / 2;
-            if (fullest(mid) <= tile_budget) lo = mid; else hi = mid - 1;
+            if (fits(mid)) lo = mid; else hi = mid - 1;
         }
         rows = lo;  // a batch is never smaller than one tile row
     }
     size_t cap_tiles = owned > 0 ? fullest(rows) : 0;
     if (cap_tiles < 1) cap_tiles = 1;
     p.rows_per_batch = rows;
-    if (tile_slots == 0 || cap_tiles > 0x7ffffff0ull / tile_slots) p.rows_per_batch = 0;  // one tile row alone exceeds the slot range: refused by the caller
+    if (tile_slots == 0 || cap_tiles > 0x7ffffff0ull / tile_slots || draws_stride > 0xfffffff0ull)
+        p.rows_per_batch = 0;  // one tile (row) alone exceeds the 32-bit index ranges: refused by the caller
     const size_t cap = cap_tiles * tile_slots;
     p.ws.cap = static_cast<uint32_t>(cap > 0xfffffff0ull ? 0xfffffff0ull : cap);
     p.ws.tile_cap = static_cast<uint32_t>(cap_tiles);
     w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 : 0;
+    w.tile_draws = static_cast<size_t>(rows) * draws_row_bytes;
     w.scol = cap * 16;
     p.ws.unit_cap = static_cast<uint32_t>(cap_tiles * static_cast<size_t>(p.parts_per_tile));
     w.units = static_cast<size_t>(p.ws.unit_cap) * 16;
@@ -1222,16 +1126,17 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
         const int batch_tiles = rows * p.shard.tiles_x;
         hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 1) * 4, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(plan_units_kernel, dim3(batch_tiles), dim3(64), 0, stream, p.scene, p, tile_base, batch_tiles);
+        hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
+                           p.scene, p.tile_rng, p.ws.tile_draws, p, tile_base, batch_tiles);
         const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
         if (p.scene_in_lds && !p.scene_posed) {
-            hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, out8, p, tile_base, batch_tiles);
+            hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewLdsUnposed>(p, stream, dyn);
         } else if (p.scene_in_lds) {
-            hipLaunchKernelGGL(primary_kernel<kViewLds>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.tile_rng, out, out8, p, tile_base, batch_tiles);
+            hipLaunchKernelGGL(primary_kernel<kViewLds>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewLds>(p, stream, dyn);
         } else {
-            hipLaunchKernelGGL(primary_kernel<kViewHbm>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.tile_rng, out, out8, p, tile_base, batch_tiles);
+            hipLaunchKernelGGL(primary_kernel<kViewHbm>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewHbm>(p, stream, 0);
         }
         const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
