@@ -155,7 +155,7 @@ int lane_count(const mcrt_scene* s, const mcrt_config& cfg, const Shard& sh) {
     return std::max(1, std::min(lanes, sh.owned_rows));
 }
 
-// Upper bound, per owned tile row of `sh`, of the tiles that plan_units can find touched by a mesh.
+// Upper bound, per owned tile row of `sh`, of the tiles that plan_tiles can find touched by a mesh.
 // It repeats the device's test (mesh_touches_tile + the thin-lens dilation) in double precision
 // with several pixels of extra margin, so it can only over-count; anything unusual → every tile.
 void touched_tiles_per_row(const mcrt_scene* sc, const mcrt_config& cfg, const Shard& sh, std::vector<int>& out) {

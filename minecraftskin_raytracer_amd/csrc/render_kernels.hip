@@ -7,27 +7,28 @@
 // workgroup, and hit work is spread over the whole chip no matter which tiles hold the character.
 //
 //   seed_tiles      1 lane / tile     mt19937 seeding of the per-tile jitter streams
-//   plan_units      1 wave / tile     which meshes' screen bounds touch the tile; a tile nothing can
-//                                     touch becomes ONE background unit, other tiles are split into
-//                                     pixel-aligned parts (load balance) with colour slots assigned
-//   primary         persistent WGs    pull units by ticket.  Background units: thread per pixel,
-//                                     jitter stream in LDS, gradient, ordered sample sum, coalesced
-//                                     float4 store.  Touched units: thread per sample, camera/lens
-//                                     ray, closest hit over the tile's mesh mask; misses write their
-//                                     sample colour, hits are appended to the level-0 queue
+//   plan_tiles      1 wave / tile     which meshes' screen bounds touch the tile (a tile nothing can touch
+//                                     is rendered whole as background; others are split into pixel-aligned
+//                                     units with colour slots assigned), then every draw of the tile's
+//                                     mt19937 stream — twisted inside the wave, no workgroup barrier — to HBM
+//   primary         persistent WGs    touched units: thread per sample, its draws, camera/lens ray, closest
+//                                     hit over the tile's mesh mask; misses write their sample colour, hits
+//                                     go to the level-0 queue.  Background tiles: thread per pixel, gradient,
+//                                     ordered sample sum, coalesced float4 / RGBA8 store
 //   per recursion level L = 0 .. maxBounces:
-//     light_samples 1 lane / hit      register-only truncated mt19937 → 2·S draws → light frame and the
-//                                     S disk sample positions (cos/sin/sqrt of independent samples interleave)
-//     shadow        1 lane / (hit, light sample)   any-hit shadow ray to the sample → lit count
-//     shade         1 lane / hit      Blinn-Phong (+AO), reflection ray, closest hit → level L+1
-//                                     queue; chains that end fold their level colours back to front
+//     light_samples 1 lane / hit      (level 0) register-only truncated mt19937 → 2·S draws → the S disk sample
+//                                     positions, and the hit's bundle mask (meshes its shadow rays can meet)
+//     shadow        1 lane / (hit, light sample)   exact any-hit test on the bundle mask → lit count
+//     ao_dirs, ao   (level 0, AO on)  hemisphere directions + ball mask per hit; any hit within the radius
+//     shade         1 lane / hit      Blinn-Phong (+AO), reflection ray, closest hit → level L+1 queue with its
+//                                     light samples (packed through LDS); ended chains fold back to front
 //   resolve         1 lane / pixel    ordered sum of the pixel's sample colours (float addition
-//                                     order is part of the result), coalesced float4 store
+//                                     order is part of the result), coalesced float4 / RGBA8 store
 // Queue entries live in HBM as SoA float4 arrays (ping-pong between levels).  Every unit owns a
 // fixed slot range (its samples); its hits are compacted to the front of that range with an LDS
 // prefix sum and a per-unit count — NO global atomics on the hot path (a returning atomic on one
 // word sustains only ~88 ops/us on this chip; per-wave queue claims made `primary` atomic-bound).
-// A frame is cut into batches of tile rows so that the worst case (every sample hits) fits.
+// A frame is cut into batches of tile rows so that the worst case (every sample of a touched tile hits) fits.
 // No MFMA: there is no dense contraction anywhere on this path.
 #include "kernels.h"
 #include "rt_core.h"
@@ -236,7 +237,7 @@ struct ViewSel<kViewHbm> {
 // ---------------------------------------------------------------------------------------------
 // queue helpers
 // ---------------------------------------------------------------------------------------------
-// counters[0]: number of planned units (one atomic add per touched tile, in plan_units)
+// counters[0]: number of planned units (one atomic add per touched tile, in plan_tiles)
 constexpr int kCntUnits = 0;
 constexpr int kCntTiles = 1;     // touched tiles of the batch so far
 constexpr int kCntOverflow = kCounterWords - 1;  // set if more tiles are touched than the host planned for (a bug: the host
