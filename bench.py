@@ -285,7 +285,7 @@ def main() -> None:
             },
             "latency_ms": round(latency_ms, 4),
             "kernel": {"pipeline_ms": round(trace_ms, 4),
-                       "note": "hipEvents on the launch stream around one frame's whole pipeline (seed, plan, primary, light_samples, "
+                       "note": "hipEvents on the launch stream around one frame's whole pipeline (seed, plan_tiles, primary, light_samples, "
                                "[shadow, shade] x levels, resolve); per-kernel split: profiles/"},
             "roofline": {
                 "bound": "hbm",
@@ -296,7 +296,7 @@ def main() -> None:
                 "traffic": traffic,
                 "kernel": "whole wavefront pipeline of one frame (dominant stage: shadow_kernel, see profiles/)",
                 "note": "algorithmic bytes = 16 B x output pixels per frame; the path is VALU/latency-bound by construction "
-                        "(DESIGN.md): VALU issue (4-cycle cadence) 41 % of one frame's chain, 72 % with four frames in flight (profiles/r01_v6)",
+                        "(DESIGN.md): VALU issue (4-cycle cadence) 40 % of one frame's chain, 73 % with four frames in flight (profiles/r01_v7)",
             },
         }
         if check is not None:
