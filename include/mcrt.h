@@ -266,7 +266,7 @@ int mcrt_probe_trace(mcrt_scene* scene, const mcrt_config* cfg, const float* ray
 /* first n outputs of uniform_real_distribution<float>(0,1) over std::mt19937(seed) for each seed */
 int mcrt_probe_mt_uniform(int device, const uint32_t* seeds, int n_seeds, int n_draws, float* out);
 /* device detmath: op 0 = sinf, 1 = cosf, 2 = powf(x, y), 3 / 4 = sin / cos output of the fused
- * mcrt_sincosf, over n inputs */
+ * mcrt_sincosf, 5 = the kernels' 3-instruction reciprocal (reference: IEEE 1.0f / x), over n inputs */
 int mcrt_probe_detmath(int device, int op, const float* x, const float* y, size_t n, float* out);
 /* device detmath range check against the host build of the same header:
  * op 0/1: all floats with bit patterns in [lo_bits, hi_bits]; op 2: powf(x, y0).

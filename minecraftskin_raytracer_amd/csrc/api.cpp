@@ -1014,7 +1014,7 @@ int mcrt_probe_mt_uniform(int device, const uint32_t* seeds, int n_seeds, int n_
 }
 
 int mcrt_probe_detmath(int device, int op, const float* x, const float* y, size_t n, float* out) {
-    if (!x || !out || op < 0 || op > 4 || (op == 2 && !y)) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (!x || !out || op < 0 || op > 5 || (op == 2 && !y)) return fail(MCRT_ERR_INVALID, "bad argument");
     if (n == 0) return MCRT_OK;
     if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device");
     HIP_TRY(hipSetDevice(device));
@@ -1037,7 +1037,7 @@ int mcrt_probe_detmath(int device, int op, const float* x, const float* y, size_
 }
 
 int mcrt_probe_detmath_range(int device, int op, uint32_t lo_bits, uint32_t hi_bits, float y0, uint64_t* mismatches) {
-    if (!mismatches || op < 0 || op > 4 || hi_bits < lo_bits) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (!mismatches || op < 0 || op > 5 || hi_bits < lo_bits) return fail(MCRT_ERR_INVALID, "bad argument");
     if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device");
     HIP_TRY(hipSetDevice(device));
     const uint64_t total = static_cast<uint64_t>(hi_bits) - lo_bits + 1;
@@ -1066,7 +1066,8 @@ int mcrt_probe_detmath_range(int device, int op, uint32_t lo_bits, uint32_t hi_b
                 for (uint64_t i = t; i < cnt; i += nt) {
                     float x = mcrt_u2f(base + static_cast<uint32_t>(i));
                     // ops 3/4 (device: the fused mcrt_sincosf) are held against the separate functions
-                    float ref = (op == 0 || op == 3) ? mcrt_sinf(x) : ((op == 1 || op == 4) ? mcrt_cosf(x) : mcrt_powf(x, y0));
+                    float ref = op == 5 ? 1.0f / x
+                                        : ((op == 0 || op == 3) ? mcrt_sinf(x) : ((op == 1 || op == 4) ? mcrt_cosf(x) : mcrt_powf(x, y0)));
                     uint32_t a = mcrt_f2u(ref), d = mcrt_f2u(host[i]);
                     if (a != d && !(std::isnan(ref) && std::isnan(host[i]))) ++b;
                 }

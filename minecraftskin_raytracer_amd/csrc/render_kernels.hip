@@ -955,6 +955,7 @@ __device__ __forceinline__ float detmath_op(int op, float x, float y) {
         mcrt_sincosf(x, &sn, &cs);
         return op == 3 ? sn : cs;
     }
+    if (op == 5) return rcp_exact(x);  // held against the host's IEEE 1.0f / x
     return op == 0 ? mcrt_sinf(x) : (op == 1 ? mcrt_cosf(x) : mcrt_powf(x, y));
 }
 __global__ void probe_detmath_kernel(int op, const float* x, const float* y, size_t n, float* out) {

@@ -49,8 +49,19 @@ DEV V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
 DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
-DEV V3 vdiv(V3 a, float s) {  // vec3.h:22
-    float inv = 1.0f / s;
+// 1.0f / x correctly rounded (== the IEEE division) for every float x with 2^-126 <= |x| <= 2^126:
+// hardware reciprocal estimate (1 ulp) and one Newton step with fused multiply-adds — 3 instructions
+// instead of the ~10 of the general division expansion.  Not a numerical argument: the equality is
+// checked for EVERY float of that range on the device (mcrt_probe_detmath_range op 5,
+// tests/test_gpu_parity.py).  The callers' operands — ray direction components that matter
+// (|d| >= 1e-8), vector lengths in [1e-8, 2e19], light distances >= 1e-6 — lie inside it.
+DEV float rcp_exact(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+DEV V3 vdiv(V3 a, float s) {  // vec3.h:22 — callers guarantee 1e-8 <= s (normalize, isInShadow)
+    float inv = rcp_exact(s);
     return V3{a.x * inv, a.y * inv, a.z * inv};
 }
 DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -259,9 +270,9 @@ DEV RayQ prepare(const Ray& r) {
     q.px = __builtin_fabsf(r.d.x) < 1e-8f;
     q.py = __builtin_fabsf(r.d.y) < 1e-8f;
     q.pz = __builtin_fabsf(r.d.z) < 1e-8f;
-    q.inv.x = q.px ? 0.0f : 1.0f / r.d.x;
-    q.inv.y = q.py ? 0.0f : 1.0f / r.d.y;
-    q.inv.z = q.pz ? 0.0f : 1.0f / r.d.z;
+    q.inv.x = q.px ? 0.0f : rcp_exact(r.d.x);  // |d| >= 1e-8 where the value is used
+    q.inv.y = q.py ? 0.0f : rcp_exact(r.d.y);
+    q.inv.z = q.pz ? 0.0f : rcp_exact(r.d.z);
     return q;
 }
 

@@ -31,6 +31,15 @@ def test_detmath_device_matches_host_on_render_domain(mcrt, gpu):
     assert mcrt.probe_detmath_range(2, 0, one_bits + 64, 16.0) == 0  # powf(x,16) on [0, 1+]
 
 
+def test_fast_reciprocal_is_the_ieee_reciprocal(mcrt, gpu):
+    """rt::rcp_exact (hardware rcp + one FMA Newton step, used for the per-ray reciprocals) against the
+    host's IEEE 1.0f / x for EVERY float with 2^-126 <= |x| <= 2^126, both signs."""
+    f = lambda v: int(np.float32(v).view(np.uint32))
+    lo, hi = f(2.0 ** -126), f(2.0 ** 126)
+    assert mcrt.probe_detmath_range(5, lo, hi) == 0
+    assert mcrt.probe_detmath_range(5, lo | 0x80000000, hi | 0x80000000) == 0
+
+
 def test_detmath_device_random(mcrt, gpu):
     g = np.random.default_rng(1)
     x = g.uniform(-200, 200, 1 << 16).astype(np.float32)
