@@ -17,6 +17,7 @@ CASES = {
     "gui_ao": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=4, aoEnabled=True, aoSamples=16)),
     "gui_dof": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=4, dofEnabled=True, aperture=0.3)),
     "spp64": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=64)),
+    "base_p6": (lambda: scenes.skin_scene("S64", 6), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=4)),  # 8 posed meshes
     "tiny": (lambda: scenes.skin_scene("S64", 0), dict(width=64, height=64, maxBounces=4, samplesPerPixel=4)),
     "8k": (lambda: scenes.skin_scene("S32", 0), dict(width=7680, height=4320, maxBounces=8, samplesPerPixel=64)),
     "4k": (lambda: scenes.skin_scene("S64", 0), dict(width=3840, height=2160, maxBounces=8, samplesPerPixel=16)),
