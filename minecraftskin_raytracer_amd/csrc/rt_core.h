@@ -713,15 +713,12 @@ DEV bool any_hit_masked(const SV& sc, const Ray& r, float limit, unsigned long l
 // O to B's farthest corner), the central segment's point at the SAME fraction s lies in B inflated
 // by s·R.  The test below solves "exists s in [0,1] with O + s·(L-O) in B inflated by s·R" exactly
 // (linear in s per axis) with generous float slack; it only ever adds candidates — the exact
-// per-ray test (any_hit_masked) decides.  Posed meshes: their bounding sphere, inflated by R times
-// the largest fraction at which the sphere can be reached.
+// per-ray test (any_hit_masked) decides.  Posed meshes: the same test with the segment rotated into
+// the mesh's local frame.
 template <bool kPosed, class SV>
 DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
     const V3 D = L - O;
-    const float dd = dot(D, D);
     const float Rb = R * 1.001f + 1e-6f;
-    const float dist_min = __builtin_sqrtf(dd) - Rb;  // the shortest ray of the bundle
-    const float inv_dist = dist_min > 1e-3f ? __builtin_amdgcn_rcpf(dist_min) * 1.001f : 3.0e38f;
     const float slack = 2e-3f;
     unsigned long long cand = 0ull;
     const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
@@ -731,28 +728,28 @@ DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
         if (!((roots >> i) & 1ull)) continue;
         const MeshData m = mesh_uniform(sc, i);
         if (m.flags & MESH_EMPTY) continue;
-        bool pass;
+        // posed mesh: the same test in the mesh's local frame — the rotation is rigid, so the bundle keeps
+        // its radius; the float error of rotating two points (~1e-5 at scene scale) is far inside the slack
+        V3 o = O, d = D;
         if (kPosed && (m.flags & MESH_ROTATED)) {
-            pass = true;
-            if (!(m.radius < 0.0f)) {
-                const V3 oc = m.centre - O;
-                const float far = __builtin_sqrtf(dot(oc, oc)) + m.radius;
-                const float frac = smin(1.0f, far * inv_dist);
-                const float rr = m.radius + Rb * frac + slack;
-                float s = dd > 1e-12f ? dot(oc, D) * __builtin_amdgcn_rcpf(dd) : 0.0f;
-                s = sclamp(s, 0.0f, 1.0f);
-                const V3 q = oc - D * s;
-                pass = !(dot(q, q) > rr * rr * 1.001f);
-            }
-        } else {
-            // C(s) = O + s·D inside the box inflated by s·Rb (+ slack), for some s in [0, 1]: per axis
-            //   (D + Rb)·s >= lo - slack - o      and      (D - Rb)·s <= hi + slack - o
+            const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
+            auto to_mesh = [&](V3 pnt) __attribute__((always_inline)) {
+                V3 q = spin(pnt, m.pivot, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
+                return spin(q, m.pivot, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
+            };
+            o = to_mesh(O);
+            d = to_mesh(L) - o;
+        }
+        bool pass;
+        {
+            // C(s) = o + s·d inside the box inflated by s·Rb (+ slack), for some s in [0, 1]: per axis
+            //   (d + Rb)·s >= lo - slack - o      and      (d - Rb)·s <= hi + slack - o
             // — linear in s, so the feasible s form an interval
             float s_in = -1e-4f, s_out = 1.0f + 1e-4f;
             bool ok = true;
-            auto axis = [&](float o, float d, float l, float h) __attribute__((always_inline)) {
-                const float al = d + Rb, bl = l - slack - o;  // al·s >= bl
-                const float ah = d - Rb, bh = h + slack - o;  // ah·s <= bh
+            auto axis = [&](float o1, float d1, float l, float h) __attribute__((always_inline)) {
+                const float al = d1 + Rb, bl = l - slack - o1;  // al·s >= bl
+                const float ah = d1 - Rb, bh = h + slack - o1;  // ah·s <= bh
                 const float ql = bl * __builtin_amdgcn_rcpf(al), qh = bh * __builtin_amdgcn_rcpf(ah);
                 const bool flat_l = __builtin_fabsf(al) < 1e-6f, flat_h = __builtin_fabsf(ah) < 1e-6f;
                 // flat: the inequality does not depend on s (holds iff 0 >= bl resp. 0 <= bh; tiny margin)
@@ -762,9 +759,9 @@ DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
                 s_out = (!flat_h & (ah > 0.0f)) ? smin(s_out, qh + 1e-5f) : s_out;
                 s_in = (!flat_h & (ah < 0.0f)) ? smax(s_in, qh - 1e-5f) : s_in;
             };
-            axis(O.x, D.x, m.lo.x, m.hi.x);
-            axis(O.y, D.y, m.lo.y, m.hi.y);
-            axis(O.z, D.z, m.lo.z, m.hi.z);
+            axis(o.x, d.x, m.lo.x, m.hi.x);
+            axis(o.y, d.y, m.lo.y, m.hi.y);
+            axis(o.z, d.z, m.lo.z, m.hi.z);
             pass = ok & !(s_in > s_out);
         }
         if (pass) cand |= m.group;
