@@ -294,7 +294,7 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "kernel": "whole wavefront pipeline of one frame (dominant stage: shadow_kernel, see profiles/)",
+                "kernel": "whole wavefront pipeline of one frame (level-0 stages: shade 92 us, shadow 78, light_samples 70, primary 54, plan_tiles 32; profiles/r01_v7)",
                 "note": "algorithmic bytes = 16 B x output pixels per frame; the path is VALU/latency-bound by construction "
                         "(DESIGN.md): VALU issue (4-cycle cadence) 40 % of one frame's chain, 73 % with four frames in flight (profiles/r01_v7)",
             },
