@@ -374,7 +374,10 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
             if (r.last_use < victim->last_use) victim = &r;
         }
         if (!slot) {  // first sighting: remember the parameters
-            if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
+            if (victim->exec) {  // evicting a recorded sequence: an earlier launch of it may still be running
+                (void)hipDeviceSynchronize();
+                (void)hipGraphExecDestroy(victim->exec);
+            }
             if (victim->graph) (void)hipGraphDestroy(victim->graph);
             victim->exec = nullptr;
             victim->graph = nullptr;
