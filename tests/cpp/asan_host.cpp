@@ -2,12 +2,44 @@
 // plus malformed descriptions.
 #include "flatten.h"
 #include "mcrt.h"
+#include <cmath>
+#include <cstdlib>
+#include <limits>
 #include <cstdio>
 #include <cstdint>
 #include <string>
 #include <vector>
-int main() {
+int mcrt_detail_fail(int code, const char*) { return code; }  // api.cpp's error hook (not linked here)
+
+static int png_checks() {
     int bad = 0;
+    const int sizes[][2] = {{1, 1}, {3, 2}, {257, 31}, {16383, 1}, {16384, 1}, {4095, 4}, {4096, 4}, {13107, 5}};
+    for (const auto& wh : sizes) {
+        const int w = wh[0], h = wh[1];
+        std::vector<uint8_t> img(static_cast<size_t>(w) * h * 4);
+        uint32_t s = 99;
+        for (auto& b : img) { s = s * 1664525u + 1013904223u; b = static_cast<uint8_t>(s >> 24); }
+        const size_t need = mcrt_encode_png_rgba8(img.data(), w, h, nullptr, 0);
+        std::vector<uint8_t> out(need);  // exactly `need` bytes: any overrun is an ASan error
+        if (!need || mcrt_encode_png_rgba8(img.data(), w, h, out.data(), out.size()) != need) ++bad;
+        if (need > 8 && mcrt_encode_png_rgba8(img.data(), w, h, out.data(), need - 1) != need) ++bad;  // too small: size only
+    }
+    // quantiser on awkward values (image_writer.cpp:18-22 semantics: clamp then *255+0.5 then truncate)
+    const float inf = std::numeric_limits<float>::infinity();
+    const float vals[8] = {-1.0f, 0.0f, 0.5f, 1.0f, 2.0f, inf, -inf, 0.99999994f};
+    uint8_t q[8];
+    mcrt_quantize_rgba8(vals, q, 2);
+    if (q[0] != 0 || q[1] != 0 || q[2] != 128 || q[3] != 255 || q[4] != 255 || q[5] != 255 || q[6] != 0 || q[7] != 255) ++bad;
+    std::vector<float> f(4 * 6, 0.25f);
+    if (mcrt_write_png_f32("/tmp/mcrt_asan_host.png", f.data(), 3, 2) != MCRT_OK) ++bad;
+    if (mcrt_write_png_f32("/nonexistent_dir_mcrt/x.png", f.data(), 3, 2) == MCRT_OK) ++bad;
+    if (mcrt_write_png_rgba8("/tmp/mcrt_asan_host.png", nullptr, 3, 2) == MCRT_OK) ++bad;
+    std::remove("/tmp/mcrt_asan_host.png");
+    return bad;
+}
+
+int main() {
+    int bad = png_checks();
     for (int legacy = 0; legacy < 2; ++legacy) {
         const int w = 64, h = legacy ? 32 : 64;
         std::vector<uint8_t> skin(static_cast<size_t>(w) * h * 4);
