@@ -294,9 +294,9 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "kernel": "whole wavefront pipeline of one frame (level-0 stages: shade 92 us, shadow 78, light_samples 70, primary 54, plan_tiles 32; profiles/r01_v7)",
+                "kernel": "whole wavefront pipeline of one frame (level-0 stages: shade 90 us, shadow 78, light_samples 70, primary 55, plan_tiles 33; profiles/r01_v8)",
                 "note": "algorithmic bytes = 16 B x output pixels per frame; the path is VALU/latency-bound by construction "
-                        "(DESIGN.md): VALU issue (4-cycle cadence) 40 % of one frame's chain, 73 % with four frames in flight (profiles/r01_v7)",
+                        "(DESIGN.md): VALU issue (4-cycle cadence) 39 % of one frame's chain, 71 % with four frames in flight (profiles/r01_v8)",
             },
         }
         if check is not None:
