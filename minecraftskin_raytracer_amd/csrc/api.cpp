@@ -89,11 +89,22 @@ int draws_per_sample(const mcrt_config& c) {
 // ms, 4K/8 bounces/16 spp 9.6 -> 5.3 ms with three lanes).  Lane 0 runs on the caller's stream,
 // the others fork from it and join it through events, so the caller sees ordinary stream order.
 constexpr int kMaxLanes = 4;
+// what the seeded per-tile mt19937 states in Lane::tile_rng are a function of (tile_renderer.cpp:78: the
+// seed is tile.y * width + tile.x) — scene and every other setting do not enter
+struct RngKey {
+    const void* ptr = nullptr;
+    int width = 0, tile_size = 0, first = 0, step = 0, tiles_x = 0, owned_rows = 0;
+    bool operator==(const RngKey& o) const {
+        return ptr == o.ptr && width == o.width && tile_size == o.tile_size && first == o.first && step == o.step && tiles_x == o.tiles_x &&
+               owned_rows == o.owned_rows;
+    }
+};
 struct Lane {
     hipStream_t stream = nullptr;  // owned; unused for lane 0
     hipEvent_t done = nullptr;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
-    DeviceBuffer tile_rng, tile_draws, scol, units, unit_hits[2], tile_mask, queues[10], targets, cand, lit[2], stack, root_sample, counters, hit_rng;
+    DeviceBuffer tile_rng, tile_draws, scol, units, unit_hits[2], tile_mask, queues[10], targets, cand, lit[2], stack, counters, hit_rng;
+    RngKey rng_key;               // which tile seeds tile_rng holds (ptr == nullptr: none)
 };
 
 struct mcrt_scene {
@@ -121,6 +132,12 @@ struct mcrt_scene {
     hipStream_t capture_stream = nullptr;
     hipEvent_t fork = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // One handle = one frame in flight: all renders of a handle share its workspace.  `last_done` is recorded
+    // at the end of every render; a render enqueued on a different stream than the previous one waits for it.
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    bool flags_checked = true;  // no render since mcrt_scene_check last read (and cleared) the lanes' overflow words
 };
 
 namespace {
@@ -261,7 +278,6 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         want(s->lit[0], w.lit);
         want(s->lit[1], w.lit);
         want(s->stack, w.stack);
-        want(s->root_sample, w.root_sample);
         {
             const void* before = s->counters.ptr;
             want(s->counters, w.counters);
@@ -278,7 +294,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         s->unit_hits[0].release(), s->unit_hits[1].release();
         for (auto& q : s->queues) q.release();
         s->targets.release(), s->cand.release(), s->lit[0].release(), s->lit[1].release(), s->stack.release();
-        s->root_sample.release(), s->counters.release(), s->hit_rng.release();
+        s->counters.release(), s->hit_rng.release();
         sc->budget /= 2;
     }
     p.tile_rng = w.tile_rng ? static_cast<uint32_t*>(s->tile_rng.ptr) : nullptr;
@@ -301,7 +317,6 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     ws.unit_hits[0] = static_cast<uint32_t*>(s->unit_hits[0].ptr);
     ws.unit_hits[1] = static_cast<uint32_t*>(s->unit_hits[1].ptr);
     ws.stack = static_cast<float4*>(s->stack.ptr);
-    ws.root_sample = static_cast<uint32_t*>(s->root_sample.ptr);
     ws.counters = static_cast<uint32_t*>(s->counters.ptr);
     ws.hit_rng = w.hit_rng ? static_cast<uint32_t*>(s->hit_rng.ptr) : nullptr;
     return MCRT_OK;
@@ -324,6 +339,14 @@ int launch_lanes(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t 
     return MCRT_OK;
 }
 
+RngKey rng_key_of(const RenderParams& p) {
+    RngKey k;
+    k.ptr = p.tile_rng;
+    k.width = p.cfg.width, k.tile_size = p.cfg.tile_size;
+    k.first = p.shard.first, k.step = p.shard.step, k.tiles_x = p.shard.tiles_x, k.owned_rows = p.shard.owned_rows;
+    return k;
+}
+
 // MCRT_GRAPH=0 turns launch recording off (every render then issues its ~17 launches per lane)
 bool graphs_enabled() {
     static const bool v = [] {
@@ -333,34 +356,17 @@ bool graphs_enabled() {
     return v;
 }
 
-// enqueue one render of the shard (first, step) on `stream`.  The launch sequence of a render is a
-// pure function of its RenderParams (all control flow that depends on data lives on the device), so
-// it is recorded once as a hipGraph — through stream capture on a private stream, lanes included —
-// and replayed with a single hipGraphLaunch whenever the same parameters come again: ~75 us of
-// launch calls per render become one.
-int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, uint8_t* d_out8,
-                   hipStream_t stream, bool may_record = true) {
-    const Shard whole = make_shard(*cfg, first, step);
-    if (whole.owned_rows <= 0) return MCRT_OK;
-    const int n_lanes = lane_count(s, *cfg, whole);
-    RenderParams p[kMaxLanes];
-    std::memset(p, 0, sizeof p);
-    for (int li = 0; li < n_lanes; ++li) {
-        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li]);
-        if (rc != MCRT_OK) return rc;
-        Lane& ln = s->lanes[li];
-        if (li > 0 && !ln.stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-        }
-    }
-    if (n_lanes > 1 && !s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+// deepest recursion the workspace is laid out for (one stack slot per level and sample; the general
+// variants also keep one queue counter per level)
+constexpr int kMaxBounces = 4000;
+
+// The launches of one render, directly or — when the same parameters keep coming — as one replayed
+// hipGraph.  The launch sequence of a render is a pure function of its RenderParams (all control flow
+// that depends on data lives on the device), so it is recorded once through stream capture on a private
+// stream, lanes included, and replayed with a single hipGraphLaunch: ~75 us of launch calls per render
+// become one.
+int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream, bool may_record) {
     if (!graphs_enabled() || !may_record) return launch_lanes(s, p, n_lanes, stream);
-
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return launch_lanes(s, p, n_lanes, stream);  // the caller is recording a graph of its own
-
     ++s->use_clock;
     mcrt_scene::Recorded* slot = nullptr;
     for (auto& r : s->recorded)
@@ -387,7 +393,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
             victim->graph = nullptr;
             victim->n_lanes = n_lanes;
             victim->sightings = 0;
-            std::memcpy(victim->p, p, sizeof p);
+            std::memcpy(victim->p, p, sizeof(RenderParams) * kMaxLanes);
             slot = victim;
         }
         slot->last_use = s->use_clock;
@@ -422,6 +428,50 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     return MCRT_OK;
 }
 
+// enqueue one render of the shard (first, step) on `stream`
+int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, uint8_t* d_out8,
+                   hipStream_t stream, bool may_record = true) {
+    const Shard whole = make_shard(*cfg, first, step);
+    if (whole.owned_rows <= 0) return MCRT_OK;
+    if (cfg->max_bounces > kMaxBounces) return fail(MCRT_ERR_INVALID, "max_bounces above 4000 is not supported (one stack slot per level and sample)");
+    const int n_lanes = lane_count(s, *cfg, whole);
+    RenderParams p[kMaxLanes];
+    std::memset(p, 0, sizeof p);
+    for (int li = 0; li < n_lanes; ++li) {
+        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li]);
+        if (rc != MCRT_OK) return rc;
+        Lane& ln = s->lanes[li];
+        if (li > 0 && !ln.stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        }
+    }
+    if (n_lanes > 1 && !s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;  // the caller records a graph of its own
+    // all renders of a handle share its workspace: they run one after the other whatever streams they are given
+    if (!capturing && s->have_last && s->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->last_done, 0));
+    s->flags_checked = false;
+    // the tiles' seeded mt19937 states: kept across renders, re-made (on the caller's stream, ahead of
+    // the lanes' fork) only when the frame width, the tile size or the shard changed
+    for (int li = 0; li < n_lanes; ++li) {
+        if (!p[li].tile_rng) continue;
+        Lane& ln = s->lanes[li];
+        const RngKey k = rng_key_of(p[li]);
+        if (!capturing && k == ln.rng_key) continue;
+        HIP_TRY(launch_seed_tiles(p[li], stream));
+        ln.rng_key = capturing ? RngKey{} : k;  // a captured seeding pass runs when the caller's graph does, not now
+    }
+    const int rc = capturing ? launch_lanes(s, p, n_lanes, stream) : launch_or_replay(s, p, n_lanes, stream, may_record);
+    if (rc == MCRT_OK && !capturing) {
+        if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(s->last_done, stream));
+        s->last_stream = stream;
+        s->have_last = true;
+    }
+    return rc;
+}
+
 }  // namespace
 
 namespace {
@@ -432,8 +482,7 @@ size_t workspace_bytes(const mcrt_scene* s) {
     for (const Lane& ln : s->lanes) {
         n += ln.tile_rng.bytes + ln.tile_draws.bytes + ln.scol.bytes + ln.units.bytes + ln.unit_hits[0].bytes + ln.unit_hits[1].bytes + ln.tile_mask.bytes;
         for (const auto& q : ln.queues) n += q.bytes;
-        n += ln.targets.bytes + ln.cand.bytes + ln.lit[0].bytes + ln.lit[1].bytes + ln.stack.bytes + ln.root_sample.bytes +
-             ln.counters.bytes + ln.hit_rng.bytes;
+        n += ln.targets.bytes + ln.cand.bytes + ln.lit[0].bytes + ln.lit[1].bytes + ln.stack.bytes + ln.counters.bytes + ln.hit_rng.bytes;
     }
     return n;
 }
@@ -548,6 +597,8 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
     }
     s->forced_lanes = 0;
     s->budget = 0;  // a budget halved under memory pressure is not inherited
+    s->have_last = false;  // a pooled shell was synchronised when its previous owner let go of it
+    s->last_stream = nullptr;
     s->alpha_words = reinterpret_cast<const FlatHeader*>(b.data())->alpha_words;
     s->n_meshes = reinterpret_cast<const FlatHeader*>(b.data())->n_meshes;
     s->posed = false;
@@ -576,6 +627,7 @@ void mcrt_scene_destroy(mcrt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();  // renders of this scene may still be running on the caller's streams
+    if (!s->flags_checked) (void)mcrt_scene_check(s);  // reads and clears the lanes' sticky overflow words: the next owner of the workspace starts clean
     // A modest workspace is kept for the next scene on this device (one idle shell per device): a fresh
     // hipMalloc of the lanes' buffers costs milliseconds per render call of the one-shot API
     // (TileRenderer::render), tens of GB for large frames take far longer.  mcrt_trim() lets go of it.
@@ -607,6 +659,7 @@ void destroy_scene_now(mcrt_scene* s) {
     }
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     if (s->fork) (void)hipEventDestroy(s->fork);
+    if (s->last_done) (void)hipEventDestroy(s->last_done);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     delete s;
@@ -617,12 +670,19 @@ int mcrt_scene_check(mcrt_scene* s) {
     if (!s) return fail(MCRT_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
+    bool flagged = false;
     for (Lane& ln : s->lanes) {
         if (!ln.counters.ptr) continue;
+        uint32_t* word = static_cast<uint32_t*>(ln.counters.ptr) + (kCounterWords - 1);
         uint32_t flag = 0;
-        HIP_TRY(hipMemcpy(&flag, static_cast<uint32_t*>(ln.counters.ptr) + (kCounterWords - 1), 4, hipMemcpyDeviceToHost));
-        if (flag) return fail(MCRT_ERR_HIP, "internal error: more tiles were touched than the workspace was planned for");
+        HIP_TRY(hipMemcpy(&flag, word, 4, hipMemcpyDeviceToHost));
+        if (flag) {  // reported once: the word is cleared so that later renders (and the next owner of a pooled workspace) start clean
+            flagged = true;
+            HIP_TRY(hipMemset(word, 0, 4));
+        }
     }
+    s->flags_checked = true;
+    if (flagged) return fail(MCRT_ERR_HIP, "internal error: more tiles were touched than the workspace was planned for");
     return MCRT_OK;
 }
 

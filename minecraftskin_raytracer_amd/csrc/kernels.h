@@ -35,7 +35,7 @@ struct WaveSpace {
     uint32_t unit_cap;      // capacity of `units`
     uint32_t tile_cap;      // tiles of a batch that may be touched by meshes (host-side superset of the device's culling):
                             // touched tile number k of a batch owns slots [k, k+1) * tile_size^2 * spp
-    float4* q_o[2];         // hit queues, ping-pong by level parity: ray origin  (.w = root entry, bit-cast)
+    float4* q_o[2];         // hit queues, ping-pong by level parity: ray origin  (.w = root = the chain's sample slot, bit-cast)
     float4* q_d[2];         //                                         ray direction (.w = depth, bit-cast)
     float4* q_p[2];         //                                         hit point
     float4* q_n[2];         //                                         hit normal (as intersectMesh returns it)
@@ -43,10 +43,9 @@ struct WaveSpace {
     float* targets;         // [cap][3*shadowSamples] light sample positions of the current level's hits
     unsigned long long* cand;  // [cap] per hit: meshes its soft-shadow rays can meet (conservative first pass, once per hit)
     uint32_t* lit[2];       // [cap] visible light samples of a level's hits (ping-pong by level parity)
-    float4* stack;          // [cap][stack_stride] level colours of the chain rooted at level-0 entry r
-    uint32_t* root_sample;  // [cap] scol slot of the sample that level-0 entry r belongs to
-    uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [last] touched-tile bound exceeded (never, by construction),
-                            // [8 + L] entries of level L >= 1
+    float4* stack;          // [cap][stack_stride] level colours of the chain of sample slot r (written only by chains that go on)
+    uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [8 + L] entries of level L >= 1,
+                            // [last] touched-tile bound exceeded (never, by construction; sticky); cleared per pass but for the last
     uint32_t* hit_rng;      // general variant: per-thread 624-word mt19937 states (long streams)
     uint32_t cap;           // entry capacity (= samples of the largest batch)
     int stack_stride;       // max(1, maxBounces)
@@ -76,7 +75,7 @@ Shard make_shard(const mcrt_config& cfg, int first, int step);
 // p.ws.cap / p.ws.stack_stride.  budget_bytes bounds the per-batch workspace (a batch is never
 // smaller than one tile row).
 struct WorkspaceBytes {
-    size_t tile_rng, tile_draws, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, root_sample, counters, hit_rng;
+    size_t tile_rng, tile_draws, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, counters, hit_rng;
 };
 // row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
 WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);
@@ -84,8 +83,11 @@ constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
 constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
 constexpr int kCounterWords = 4096;
 
-// enqueue the whole pipeline of one lane on `stream`: tile-RNG seeding (if needed), then per batch of
-// tile rows plan → primary → [light_samples, shadow, (ao_dirs, ao,) shade] per level → resolve
+// seeds p.tile_rng: one mt19937 per owned tile (tile_renderer.cpp:78).  A function of the frame width, the
+// tile size and the shard only — the caller keeps the result across renders and calls this when those change.
+hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream);
+// enqueue the whole pipeline of one lane on `stream` (p.tile_rng already seeded): per batch of tile rows
+// plan → primary → light_samples, shadow, (ao_dirs, ao,) shade of level 0 → tail (all deeper levels) → resolve
 hipError_t launch_render(const RenderParams& p, hipStream_t stream);
 
 hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const float* packed, float* frame,

@@ -6,7 +6,8 @@
 // the dependent slab tests of a shadow ray) are hidden by many resident waves instead of stalling a
 // workgroup, and hit work is spread over the whole chip no matter which tiles hold the character.
 //
-//   seed_tiles      1 lane / tile     mt19937 seeding of the per-tile jitter streams
+//   seed_tiles      1 lane / tile     mt19937 seeding of the per-tile jitter streams (kept across renders: the
+//                                     seeds depend on the frame width, the tile size and the shard only)
 //   plan_tiles      1 wave / tile     which meshes' screen bounds touch the tile (a tile nothing can touch
 //                                     is rendered whole as background; others are split into pixel-aligned
 //                                     units with colour slots assigned), then every draw of the tile's
@@ -15,13 +16,17 @@
 //                                     hit over the tile's mesh mask; misses write their sample colour, hits
 //                                     go to the level-0 queue.  Background tiles: thread per pixel, gradient,
 //                                     ordered sample sum, coalesced float4 / RGBA8 store
-//   per recursion level L = 0 .. maxBounces:
-//     light_samples 1 lane / hit      (level 0) register-only truncated mt19937 → 2·S draws → the S disk sample
+//   level 0 (the primary hits, ~7 % of the samples):
+//     light_samples 1 lane / hit      register-only truncated mt19937 → 2·S draws → the S disk sample
 //                                     positions, and the hit's bundle mask (meshes its shadow rays can meet)
 //     shadow        1 lane / (hit, light sample)   exact any-hit test on the bundle mask → lit count
-//     ao_dirs, ao   (level 0, AO on)  hemisphere directions + ball mask per hit; any hit within the radius
-//     shade         1 lane / hit      Blinn-Phong (+AO), reflection ray, closest hit → level L+1 queue with its
-//                                     light samples (packed through LDS); ended chains fold back to front
+//     ao_dirs, ao   (AO on)           hemisphere directions + ball mask per hit; any hit within the radius
+//     shade         1 lane / hit      Blinn-Phong (+AO), reflection ray, closest hit → level-1 queue (~1 % of
+//                                     the hits); ended chains write their sample colour
+//   tail            S lanes / chain   ALL deeper levels in one launch: a group of lanes follows a chain to its end —
+//                                     seeding, its S shadow rays (one per lane, ballot), shade, bounce, closest hit —
+//                                     with the chain in registers; then folds the level colours back to front
+//   (general variants — per-hit RNG streams longer than 227 draws — keep one launch set per level)
 //   resolve         1 lane / pixel    ordered sum of the pixel's sample colours (float addition
 //                                     order is part of the result), coalesced float4 / RGBA8 store
 // Queue entries live in HBM as SoA float4 arrays (ping-pong between levels).  Every unit owns a
@@ -424,8 +429,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
             const int rank = block_rank(is_hit, s_wcnt, total);
             if (is_hit) {
                 const uint32_t e = slot_base + unit_hits + static_cast<uint32_t>(rank);
-                push_entry(ws, 0, e, ray, hit, e, 0);
-                ws.root_sample[e] = sample_slot;
+                push_entry(ws, 0, e, ray, hit, sample_slot, 0);  // root of the chain = its sample's colour slot
             }
             unit_hits += static_cast<uint32_t>(total);
         }
@@ -491,6 +495,13 @@ __device__ __forceinline__ void for_each_entry_block(const WaveSpace& ws, int le
         for (uint32_t k0 = blockIdx.x * kBlock; k0 < count; k0 += gridDim.x * kBlock)
             body(k0, min(static_cast<uint32_t>(kBlock), count - k0));
     }
+}
+
+// True when this workgroup will get no entry block of `level`: it can leave before it stages the scene
+// tables (a deep level holds a few thousand entries, yet every workgroup of the launch used to stage 8.7 KB).
+__device__ __forceinline__ bool no_entry_blocks(const WaveSpace& ws, int level) {
+    if (level == 0) return blockIdx.x >= ws.counters[kCntUnits];
+    return static_cast<unsigned long long>(blockIdx.x) * kBlock >= ws.counters[kCntDense + level];
 }
 
 // The S light sample positions of one hit: mt19937(shadow seed) → 2·S draws → disk samples
@@ -573,15 +584,20 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
                                                         const int level) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
-    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const WaveSpace& ws = p.ws;
     const int par = level & 1;
-    const int mode = shadow_mode(sc, p.cfg);
+    const int mode = shadow_mode(scg, p.cfg);
     const int S = p.cfg.shadow_samples;
     const uint32_t pairs_per_hit = (mode == SHADOW_SOFT) ? static_cast<uint32_t>(S) : 1u;
     // groups of pairs_per_hit consecutive lanes belong to one hit; when that is a power of two
     // <= 64 the lit count is a ballot + popcount, otherwise atomics on a zeroed counter
     const bool pow2 = (pairs_per_hit & (pairs_per_hit - 1u)) == 0u && pairs_per_hit <= 64u;
+    if (level > 0 && pow2) {  // strides over pairs (below)
+        if (static_cast<unsigned long long>(blockIdx.x) * kBlock >= static_cast<unsigned long long>(ws.counters[kCntDense + level]) * pairs_per_hit) return;
+    } else if (no_entry_blocks(ws, level)) {
+        return;
+    }
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const V3 lpos = ld3(sc.hdr->light_pos);
     const uint32_t lane = threadIdx.x & 63u;
     // one wave-aligned group of up to 64 consecutive (entry, sample) pairs of the range `first` .. +total
@@ -682,8 +698,9 @@ template <int kView>
 __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
-    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const WaveSpace& ws = p.ws;
+    if (no_entry_blocks(ws, 0)) return;
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const uint32_t A = static_cast<uint32_t>(p.cfg.ao_samples);
     const float radius = p.cfg.ao_radius;
     const bool pow2 = (A & (A - 1u)) == 0u && A <= 64u;
@@ -722,18 +739,22 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uin
     });
 }
 
-// shade: colour of the level, reflection ray, closest hit of the next level
+// shade: colour of the level, reflection ray, closest hit of the next level → survivors to the queue of
+// level + 1.  kGeneral = false: level 0 only — `tail` takes every deeper level, survivors' light samples
+// included.  kGeneral = true (per-hit RNG streams longer than the register engine): one launch per level; the
+// survivors' light samples are produced here, packed.
 template <int kView, bool kGeneral>
 __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
                                                        const int level) {
     __shared__ int s_wcnt[kBlock / 64];
     __shared__ uint32_t s_out_base;
-    __shared__ float4 s_np[kBlock], s_nn[kBlock];  // new hits (point + depth, normal) handed to the packed threads
+    __shared__ float4 s_np[kGeneral ? kBlock : 1], s_nn[kGeneral ? kBlock : 1];  // new hits handed to the packed threads
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
+    const WaveSpace& ws = p.ws;
+    if (no_entry_blocks(ws, level)) return;  // before the collective staging
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const mcrt_config& cfg = p.cfg;
-    const WaveSpace& ws = p.ws;
     const int par = level & 1;
     const int mode = shadow_mode(sc, cfg);
     const int S = cfg.shadow_samples;
@@ -782,26 +803,26 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
             }
             bool done = false;
             C4 tail = flat_bg;
-            int pushed = depth;
             if (depth >= cfg.max_bounces) {  // no reflection: `shadedColor.a = originalAlpha; return clamp()`
                 tail = clamp4(c);
                 done = true;
             } else {
-                ws.stack[static_cast<size_t>(root) * stride + depth] = make_float4(c.r, c.g, c.b, c.a);
-                pushed = depth + 1;
                 nray = reflect_ray(ray, hit);
                 nhit = hit_scene(sc, nray, ~0ull);
-                if (nhit.hit)
+                if (nhit.hit) {  // the chain goes on (~1 % of the hits): its level colour waits on the stack for the fold
+                    ws.stack[static_cast<size_t>(root) * stride + depth] = make_float4(c.r, c.g, c.b, c.a);
                     next_hit = true;
-                else
-                    done = true;  // bounced ray missed → flat background (raytracer.cpp:94-102)
-            }
-            if (done) {  // unwind the recursion: fold the level colours back to front
-                for (int d = pushed - 1; d >= 0; --d) {
-                    const float4 s = ws.stack[static_cast<size_t>(root) * stride + d];
-                    tail = fold_reflection(C4{s.x, s.y, s.z, s.w}, tail);
+                } else {  // bounced ray missed → flat background (raytracer.cpp:94-102), folded in at once (:143-147)
+                    tail = fold_reflection(c, flat_bg);
+                    done = true;
                 }
-                ws.scol[ws.root_sample[root]] = make_float4(tail.r, tail.g, tail.b, tail.a);
+            }
+            if (done) {  // unwind the recursion: fold the shallower levels' colours back to front
+                for (int d = depth - 1; d >= 0; --d) {
+                    const float4 sd = ws.stack[static_cast<size_t>(root) * stride + d];
+                    tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
+                }
+                ws.scol[root] = make_float4(tail.r, tail.g, tail.b, tail.a);
             }
         }
         // survivors → dense level+1 queue: one atomic per block
@@ -809,26 +830,164 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
         const int rank = block_rank(next_hit, s_wcnt, total);
         if (total > 0) {  // uniform
             if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
-            const bool soft = mode == SHADOW_SOFT;
-            if (next_hit && soft) {  // hand the new hit to thread `rank`: the survivors' work below runs packed
-                s_np[rank] = make_float4(nhit.p.x, nhit.p.y, nhit.p.z, __int_as_float(depth + 1));
-                s_nn[rank] = make_float4(nhit.n.x, nhit.n.y, nhit.n.z, 0.0f);
+            const bool soft = kGeneral && mode == SHADOW_SOFT;
+            if constexpr (kGeneral) {
+                if (next_hit && soft) {  // hand the new hit to thread `rank`: the survivors' work below runs packed
+                    s_np[rank] = make_float4(nhit.p.x, nhit.p.y, nhit.p.z, __int_as_float(depth + 1));
+                    s_nn[rank] = make_float4(nhit.n.x, nhit.n.y, nhit.n.z, 0.0f);
+                }
             }
             __syncthreads();
             if (next_hit) push_entry(ws, par ^ 1, s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, depth + 1);
-            // The new entries' light samples (397-step seeding chain + S samples) and bundle masks.  Only a
-            // few lanes per wave survive; done in place every wave would pay for the whole chain at ~10 %
-            // lane use.  Threads 0 .. total-1 do it instead, so the chain runs in ceil(total / 64) waves.
-            if (soft && static_cast<int>(threadIdx.x) < total) {
-                const float4 np = s_np[threadIdx.x], nn = s_nn[threadIdx.x];
-                typename SampleRng<kGeneral>::type rng;
-                const V3 P = mk(np.x, np.y, np.z);
-                seed_light_rng<kGeneral>(rng, P, __float_as_int(np.w), S, my_rng);
-                write_light_samples<kView != kViewLdsUnposed>(scg, ws, s_out_base + threadIdx.x, P, mk(nn.x, nn.y, nn.z), S, rng);
+            if constexpr (kGeneral) {
+                // The new entries' light samples (seeding chain + S samples) and bundle masks.  Only a few lanes
+                // per wave survive; threads 0 .. total-1 do it instead, so the chain runs in ceil(total / 64) waves.
+                if (soft && static_cast<int>(threadIdx.x) < total) {
+                    const float4 np = s_np[threadIdx.x], nn = s_nn[threadIdx.x];
+                    typename SampleRng<kGeneral>::type rng;
+                    const V3 P = mk(np.x, np.y, np.z);
+                    seed_light_rng<kGeneral>(rng, P, __float_as_int(np.w), S, my_rng);
+                    write_light_samples<kView != kViewLdsUnposed>(scg, ws, s_out_base + threadIdx.x, P, mk(nn.x, nn.y, nn.z), S, rng);
+                }
             }
             __syncthreads();
         }
     });
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail: every recursion level below the first bounce, in ONE launch (RayTracer::traceRay's recursion,
+// raytracer.cpp:133-144, for the chains whose first reflection ray hit something: ~1 % of the primary
+// hits, thinning out by another ~100x per level).  Launching light_samples / shadow / shade once per
+// level cost ~40 us per level of pure dependent latency for a few thousand — then a few dozen —
+// entries.  Here a group of G = min(64, pow2 >= S) lanes takes one chain and keeps it in registers to
+// its end: every lane seeds the hit's mt19937 (redundantly: the 397-step chain is sequential, the
+// lanes of a wave run it at the cost of one), lane j skips to draws 2j, 2j+1, forms light sample j
+// and traces shadow ray j; a ballot counts the lit samples; every lane of the group shades,
+// reflects and finds the next closest hit (redundantly again — lane-parallel work is free here,
+// dependent latency is not); lane 0 of the group keeps the level colours on the chain's stack and
+// folds them back to front when the chain ends.  Nothing but the chain's final colour reaches HBM.
+// Hard shadows: G = 1, a lane per chain.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTailGrid = 1024;
+constexpr int kTailFrom = 2;  // first level `tail` takes
+template <int kView>
+__global__ __launch_bounds__(kBlock) void tail_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p, const int start_level) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const SceneView scg = view_of(scene_blob);
+    const WaveSpace& ws = p.ws;
+    const mcrt_config& cfg = p.cfg;
+    const int par = start_level & 1;
+    const uint32_t count = ws.counters[kCntDense + start_level];
+    const int mode = shadow_mode(scg, cfg);
+    const uint32_t S = static_cast<uint32_t>(cfg.shadow_samples);
+    const uint32_t pairs = (mode == SHADOW_SOFT) ? S : 1u;
+    uint32_t G = 1u;
+    while (G < pairs && G < 64u) G <<= 1;
+    const uint32_t chains_per_block = kBlock / G;
+    if (static_cast<unsigned long long>(blockIdx.x) * chains_per_block >= count) return;  // uniform; before the collective staging
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
+    constexpr bool kPosed = kView != kViewLdsUnposed;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gl = threadIdx.x & (G - 1u);  // lane within its chain's group
+    const uint32_t gshift = lane - gl;           // the group's first lane within the wave
+    const unsigned long long gmask = (G == 64u) ? ~0ull : ((1ull << G) - 1ull);
+    const uint32_t rounds = (pairs + G - 1u) / G;  // light samples per lane (1 unless S > 64)
+    const V3 lpos = ld3(scg.hdr->light_pos);
+    const float lradius = scg.hdr->light_radius;
+    const int stride = ws.stack_stride;
+    const float* fb = scg.hdr->background;
+    const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
+    const unsigned long long step = static_cast<unsigned long long>(gridDim.x) * chains_per_block;
+    // no workgroup barrier below: the waves of a block advance independently
+    for (unsigned long long c0 = static_cast<unsigned long long>(blockIdx.x) * chains_per_block; c0 < count; c0 += step) {
+        const unsigned long long c = c0 + threadIdx.x / G;
+        bool active = c < count;
+        Ray ray{mk(0, 0, 0), mk(0, 0, 0)};
+        Hit hit;
+        hit.hit = true;
+        hit.outer = false;
+        hit.t = 0.0f;
+        hit.p = mk(0, 0, 0);
+        hit.n = mk(0, 0, 0);
+        hit.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
+        uint32_t root = 0;
+        int depth = start_level;
+        if (active) {  // the entry as `shade` pushed it
+            const float4 qo = ws.q_o[par][c], qd = ws.q_d[par][c], qp = ws.q_p[par][c], qn = ws.q_n[par][c], qt = ws.q_t[par][c];
+            root = __float_as_uint(qo.w);
+            depth = __float_as_int(qd.w);
+            ray = Ray{mk(qo.x, qo.y, qo.z), mk(qd.x, qd.y, qd.z)};
+            hit.p = mk(qp.x, qp.y, qp.z);
+            hit.n = mk(qn.x, qn.y, qn.z);
+            hit.tex = C4{qt.x, qt.y, qt.z, qt.w};
+        }
+        while (__ballot(active) != 0ull) {  // wave-uniform: one level of every live chain of the wave per turn
+            // ---- visibility of the light from the hit (raytracer.cpp:107-115, shading.cpp:28-60)
+            uint32_t lit = 0u;
+            if (mode == SHADOW_SOFT) {
+                MtShort rng;
+                rng.lo = rng.hi = rng.i = 0u;
+                unsigned long long cand = 0ull;
+                LightFrame frame{mk(0, 0, 0), mk(0, 0, 0)};
+                if (active) {
+                    rng.seed(shadow_seed(hit.p, depth));
+                    cand = bundle_candidates<kPosed>(scg, hit.p + hit.n * 1e-3f, lpos, lradius);
+                    frame = light_frame(scg, hit.p);
+                }
+                for (uint32_t r = 0; r < rounds; ++r) {  // uniform trip count
+                    const uint32_t smp = r * G + gl;
+                    bool vis = false;
+                    if (active && smp < S) {
+                        while (rng.i < 2u * smp) rng.skip();  // sample i takes draws 2i, 2i+1 of the hit's stream (shading.cpp:46-47)
+                        const float d0 = rng.uniform();
+                        const float d1 = rng.uniform();
+                        vis = !in_shadow_masked(sc, hit.p, hit.n, light_sample_on_frame(scg, frame, d0, d1), cand);
+                    }
+                    const unsigned long long m = __ballot(vis);
+                    lit += static_cast<uint32_t>(__popcll((m >> gshift) & gmask));
+                }
+            } else if (active) {
+                V3 N = hit.n;
+                if (mode == SHADOW_HARD) N = normalize(N);
+                lit = in_shadow_inline(sc, hit.p, N, lpos) ? 0u : 1u;
+            }
+            // ---- colour of the level, reflection, next closest hit (raytracer.cpp:117-144)
+            if (active) {
+                const float vis =
+                    (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
+                const C4 c = shade(sc, hit, normalize(ray.o - hit.p), vis);
+                bool done = false;
+                C4 tail = flat_bg;
+                if (depth >= cfg.max_bounces) {
+                    tail = clamp4(c);
+                    done = true;
+                } else {
+                    const Ray nray = reflect_ray(ray, hit);
+                    const Hit nhit = hit_scene(sc, nray, ~0ull);
+                    if (nhit.hit) {
+                        if (gl == 0u) ws.stack[static_cast<size_t>(root) * stride + depth] = make_float4(c.r, c.g, c.b, c.a);
+                        ray = nray;
+                        hit = nhit;
+                        ++depth;
+                    } else {
+                        tail = fold_reflection(c, flat_bg);
+                        done = true;
+                    }
+                }
+                if (done) {
+                    if (gl == 0u) {  // the lane that wrote the chain's stack reads it back
+                        for (int d = depth - 1; d >= 0; --d) {
+                            const float4 sd = ws.stack[static_cast<size_t>(root) * stride + d];
+                            tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
+                        }
+                        ws.scol[root] = make_float4(tail.r, tail.g, tail.b, tail.a);
+                    }
+                    active = false;
+                }
+            }
+        }
+    }
 }
 
 // resolve: ordered per-pixel sum of the queued units' sample colours (tile_renderer.cpp:116-124)
@@ -995,9 +1154,8 @@ static bool needs_general_variant(const mcrt_config& c) {
 }
 
 // Parts of a tile that meshes can touch: one 256-sample chunk each, at most 16 — fine enough that
-// the few tiles holding the character spread over the chip.  Parts of one tile share its RNG
-// stream; a later part catches up by twisting from the seeded state (tile draws / 624 twists at
-// worst), cheap next to the rays of a touched tile.  Background tiles are never split.
+// the few tiles holding the character spread over the chip.  Every part reads its samples' draws from
+// the tile's stream in HBM (plan_tiles).  Background tiles are never split.
 static int choose_parts_per_tile(const mcrt_config& cfg) {
     const long long spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const long long tile_items = static_cast<long long>(cfg.tile_size) * cfg.tile_size * spp;
@@ -1020,7 +1178,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
     const size_t A = c.ao_enabled && c.ao_samples > 0 ? static_cast<size_t>(c.ao_samples) : 0;
     const size_t rays = S > A ? S : A;  // light samples and AO directions share one array
-    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + (rays ? 8 : 0) + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride) + 4;
+    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + (rays ? 8 : 0) + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
     const int owned = p.shard.owned_rows;
     auto row_count = [&](int j) -> size_t { return row_touched ? static_cast<size_t>(row_touched[j]) : static_cast<size_t>(p.shard.tiles_x); };
     // touched tiles of the fullest batch when the shard is cut into batches of R owned rows
@@ -1075,7 +1233,6 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     w.cand = rays ? cap * 8 : 0;
     w.lit = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
-    w.root_sample = cap * 4;
     w.counters = static_cast<size_t>(kCounterWords) * 4;
     w.hit_rng = needs_general_variant(c) ? static_cast<size_t>(256) * kBlock * 624 * 4 : 0;  // general grids are capped at 256 WGs
     return w;
@@ -1093,30 +1250,45 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         return v > 0 ? v : kQueueGrid;
     }();
     const int grid = general ? 256 : tuned_grid;
-    for (int L = 0; L < levels; ++L) {
-        if (soft && L == 0) {  // deeper levels: `shade` emits the samples of the entries it appends
-            constexpr bool posed = kView != kViewLdsUnposed;
-            if (general)
-                hipLaunchKernelGGL((light_samples_kernel<true, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
-            else
-                hipLaunchKernelGGL((light_samples_kernel<false, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
+    constexpr bool posed = kView != kViewLdsUnposed;
+    if (general) {  // one launch set per level; `shade` emits the light samples of the entries it appends
+        for (int L = 0; L < levels; ++L) {
+            if (soft && L == 0) hipLaunchKernelGGL((light_samples_kernel<true, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
+            hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+            hipLaunchKernelGGL((shade_kernel<kView, true>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
         }
+        return;
+    }
+    // Levels 0 and 1 are dense enough for lane-efficient stages (a 64x64 skin with its outer layer: ~7 % of the
+    // samples hit, ~10 % of the reflection rays hit again — 550 k, 55 k, 5 k, ... entries at 1080p / 4 spp); from
+    // level kTailFrom on, one `tail` launch follows every remaining chain to its end.
+    static const int tail_from = [] {  // development knob
+        const char* e = getenv("MCRT_TAIL_FROM");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : kTailFrom;
+    }();
+    for (int L = 0; L < levels && L < tail_from; ++L) {
+        if (soft) hipLaunchKernelGGL((light_samples_kernel<false, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
         hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
-        if (L == 0 && c.ao_enabled && c.ao_samples > 0 && !general) {
-            hipLaunchKernelGGL(ao_dirs_kernel<kView != kViewLdsUnposed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
+        if (L == 0 && c.ao_enabled && c.ao_samples > 0) {
+            hipLaunchKernelGGL(ao_dirs_kernel<posed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
             hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
         }
-        if (general)
-            hipLaunchKernelGGL((shade_kernel<kView, true>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
-        else
-            hipLaunchKernelGGL((shade_kernel<kView, false>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+        hipLaunchKernelGGL((shade_kernel<kView, false>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
     }
+    if (levels > tail_from) hipLaunchKernelGGL(tail_kernel<kView>, dim3(kTailGrid), dim3(kBlock), dyn, stream, p.scene, p, tail_from);
+}
+
+hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
+    const int n = owned_tiles(p);
+    if (n <= 0 || p.draws_per_sample <= 0 || !p.tile_rng) return hipSuccess;
+    hipLaunchKernelGGL(seed_tiles_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
     const int n = owned_tiles(p);
     if (n <= 0) return hipSuccess;
-    if (p.draws_per_sample > 0) hipLaunchKernelGGL(seed_tiles_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
     const size_t dyn = p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_face_entries / 6) * kMeshTabWords * 4 +
                                             static_cast<size_t>(p.lds_alpha_words) * 4
                                       : 0;
@@ -1126,6 +1298,8 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
         const int rows = p.rows_per_batch < p.shard.owned_rows - r0 ? p.rows_per_batch : p.shard.owned_rows - r0;
         const int tile_base = r0 * p.shard.tiles_x;
         const int batch_tiles = rows * p.shard.tiles_x;
+        // (Clearing the counters from the pass's last kernel instead — the last workgroup of `resolve` to finish —
+        // was tried: its 4096 returning atomics on one ticket word took 85 us, the ~88 ops/us of one address.)
         hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 1) * 4, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,

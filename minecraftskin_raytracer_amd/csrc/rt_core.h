@@ -205,6 +205,12 @@ struct MtShort {
         ++i;
         return mt_to_unit(y);
     }
+    // advance past one draw without producing it (a lane that takes draws 2j, 2j+1 of a hit's stream)
+    DEV void skip() {
+        lo = mt_step(lo, i + 1);
+        hi = mt_step(hi, i + 398);
+        ++i;
+    }
 };
 
 // Full engine over caller-provided storage, for streams longer than kMtShortMax draws
@@ -664,14 +670,7 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
 template <class SV>
 DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
     const RayQ q = prepare(r);
-#if defined(MCRT_ABL_NO_PHASE1)   // instruction-count ablations only (results are wrong)
-    unsigned long long cand = (1ull << (sc.n_meshes < 64 ? sc.n_meshes : 63)) - 1ull;
-#else
     unsigned long long cand = scene_candidates(sc, q, ~0ull, limit);
-#endif
-#if defined(MCRT_ABL_NO_PHASE2)
-    return cand == 0x123456789abcull;
-#endif
     while (cand) {
         const int i = __builtin_ctzll(cand);
         cand &= cand - 1ull;
