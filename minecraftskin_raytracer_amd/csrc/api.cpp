@@ -103,7 +103,7 @@ struct Lane {
     hipStream_t stream = nullptr;  // owned; unused for lane 0
     hipEvent_t done = nullptr;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
-    DeviceBuffer tile_rng, tile_draws, scol, units, unit_hits[2], tile_mask, queues[10], targets, cand, lit[2], stack, counters, hit_rng;
+    DeviceBuffer tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queues[5], targets, cand, lit[2], stack, counters, hit_rng;
     RngKey rng_key;               // which tile seeds tile_rng holds (ptr == nullptr: none)
 };
 
@@ -268,15 +268,15 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         want(s->tile_rng, w.tile_rng);
         want(s->tile_draws, w.tile_draws);
         want(s->scol, w.scol);
+        want(s->end, w.end);
         want(s->units, w.units);
         want(s->tile_mask, w.tile_mask);
-        want(s->unit_hits[0], w.unit_hits);
-        want(s->unit_hits[1], w.unit_hits);
+        want(s->unit_hits, w.unit_hits);
         for (auto& q : s->queues) want(q, w.queue_each);
         want(s->targets, w.targets);
         want(s->cand, w.cand);
-        want(s->lit[0], w.lit);
-        want(s->lit[1], w.lit);
+        want(s->lit[0], w.lit0);
+        want(s->lit[1], w.lit1);
         want(s->stack, w.stack);
         {
             const void* before = s->counters.ptr;
@@ -290,8 +290,8 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
             return hip_fail(e, "workspace allocation");
         // make room: this lane's partially grown buffers go, then try again with half the budget
         (void)hipDeviceSynchronize();
-        s->tile_rng.release(), s->tile_draws.release(), s->scol.release(), s->units.release(), s->tile_mask.release();
-        s->unit_hits[0].release(), s->unit_hits[1].release();
+        s->tile_rng.release(), s->tile_draws.release(), s->scol.release(), s->end.release(), s->units.release(), s->tile_mask.release();
+        s->unit_hits.release();
         for (auto& q : s->queues) q.release();
         s->targets.release(), s->cand.release(), s->lit[0].release(), s->lit[1].release(), s->stack.release();
         s->counters.release(), s->hit_rng.release();
@@ -301,21 +301,21 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     WaveSpace& ws = p.ws;
     ws.tile_draws = static_cast<float*>(s->tile_draws.ptr);
     ws.scol = static_cast<float4*>(s->scol.ptr);
+    ws.end = static_cast<uint32_t*>(s->end.ptr);
     ws.units = static_cast<uint4*>(s->units.ptr);
     ws.tile_mask = static_cast<unsigned long long*>(s->tile_mask.ptr);
-    for (int k = 0; k < 2; ++k) {
-        ws.q_o[k] = static_cast<float4*>(s->queues[0 + k].ptr);
-        ws.q_d[k] = static_cast<float4*>(s->queues[2 + k].ptr);
-        ws.q_p[k] = static_cast<float4*>(s->queues[4 + k].ptr);
-        ws.q_n[k] = static_cast<float4*>(s->queues[6 + k].ptr);
-        ws.q_t[k] = static_cast<float4*>(s->queues[8 + k].ptr);
+    for (int k = 0; k < 2; ++k) {  // [1] = [0] + cap: the second ping-pong queue (general variants) = the deep records (flat pipeline)
+        ws.q_o[k] = static_cast<float4*>(s->queues[0].ptr) + static_cast<size_t>(k) * ws.cap;
+        ws.q_d[k] = static_cast<float4*>(s->queues[1].ptr) + static_cast<size_t>(k) * ws.cap;
+        ws.q_p[k] = static_cast<float4*>(s->queues[2].ptr) + static_cast<size_t>(k) * ws.cap;
+        ws.q_n[k] = static_cast<float4*>(s->queues[3].ptr) + static_cast<size_t>(k) * ws.cap;
+        ws.q_t[k] = static_cast<float4*>(s->queues[4].ptr) + static_cast<size_t>(k) * ws.cap;
     }
     ws.targets = static_cast<float*>(s->targets.ptr);
     ws.cand = static_cast<unsigned long long*>(s->cand.ptr);
     ws.lit[0] = static_cast<uint32_t*>(s->lit[0].ptr);
     ws.lit[1] = static_cast<uint32_t*>(s->lit[1].ptr);
-    ws.unit_hits[0] = static_cast<uint32_t*>(s->unit_hits[0].ptr);
-    ws.unit_hits[1] = static_cast<uint32_t*>(s->unit_hits[1].ptr);
+    ws.unit_hits = static_cast<uint32_t*>(s->unit_hits.ptr);
     ws.stack = static_cast<float4*>(s->stack.ptr);
     ws.counters = static_cast<uint32_t*>(s->counters.ptr);
     ws.hit_rng = w.hit_rng ? static_cast<uint32_t*>(s->hit_rng.ptr) : nullptr;
@@ -480,7 +480,7 @@ void destroy_scene_now(mcrt_scene* s);
 size_t workspace_bytes(const mcrt_scene* s) {
     size_t n = s->blob.bytes;
     for (const Lane& ln : s->lanes) {
-        n += ln.tile_rng.bytes + ln.tile_draws.bytes + ln.scol.bytes + ln.units.bytes + ln.unit_hits[0].bytes + ln.unit_hits[1].bytes + ln.tile_mask.bytes;
+        n += ln.tile_rng.bytes + ln.tile_draws.bytes + ln.scol.bytes + ln.end.bytes + ln.units.bytes + ln.unit_hits.bytes + ln.tile_mask.bytes;
         for (const auto& q : ln.queues) n += q.bytes;
         n += ln.targets.bytes + ln.cand.bytes + ln.lit[0].bytes + ln.lit[1].bytes + ln.stack.bytes + ln.counters.bytes + ln.hit_rng.bytes;
     }

@@ -24,31 +24,40 @@ struct Shard {
 };
 
 // Device workspace of the wavefront pipeline (all HBM; sized for one batch of tile rows in which
-// every sample may hit).
+// every sample may hit).  A *slot* is one sample of a tile that meshes can touch; a *record* is one hit
+// of a chain (the primary hit of a sample and every reflection hit below it).
 struct WaveSpace {
-    float4* scol;           // per-sample colours of the units that were handed to the queues
+    float4* scol;           // [cap] per-sample colour, where the sample did not start a chain (miss, background)
+    uint32_t* end;          // [cap] per sample: 0 = the colour is in `scol`; else how its chain ended:
+                            //       (records of the chain << 1) | (1 = stopped at maxBounces, 0 = the last reflection ray missed)
     uint4* units;           // units of the tiles meshes can touch: {owned tile, first pixel, end pixel, slot base}
-    uint32_t* unit_hits[2]; // per unit: live hit entries of the current / next level (ping-pong by level parity)
+    uint32_t* unit_hits;    // per unit: its primary hits (their records sit at the front of the unit's slot range)
     unsigned long long* tile_mask;  // per owned tile: meshes whose screen bound touches it
     float* tile_draws;      // [tiles of the batch][draws_stride] every draw of a tile's mt19937 stream, as uniform floats
-    uint32_t draws_stride;  // tile_size^2 * spp * draws_per_sample
+    uint32_t draws_stride;  // tile slots * draws_per_sample
     uint32_t unit_cap;      // capacity of `units`
     uint32_t tile_cap;      // tiles of a batch that may be touched by meshes (host-side superset of the device's culling):
-                            // touched tile number k of a batch owns slots [k, k+1) * tile_size^2 * spp
-    float4* q_o[2];         // hit queues, ping-pong by level parity: ray origin  (.w = root = the chain's sample slot, bit-cast)
-    float4* q_d[2];         //                                         ray direction (.w = depth, bit-cast)
-    float4* q_p[2];         //                                         hit point
-    float4* q_n[2];         //                                         hit normal (as intersectMesh returns it)
-    float4* q_t[2];         //                                         texel colour
-    float* targets;         // [cap][3*shadowSamples] light sample positions of the current level's hits
-    unsigned long long* cand;  // [cap] per hit: meshes its soft-shadow rays can meet (conservative first pass, once per hit)
-    uint32_t* lit[2];       // [cap] visible light samples of a level's hits (ping-pong by level parity)
-    float4* stack;          // [cap][stack_stride] level colours of the chain of sample slot r (written only by chains that go on)
-    uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [8 + L] entries of level L >= 1,
-                            // [last] touched-tile bound exceeded (never, by construction; sticky); cleared per pass but for the last
-    uint32_t* hit_rng;      // general variant: per-thread 624-word mt19937 states (long streams)
-    uint32_t cap;           // entry capacity (= samples of the largest batch)
-    int stack_stride;       // max(1, maxBounces)
+                            // touched tile number k of a batch owns slots [k, k+1) * tile_slots
+    // Hit records, SoA.  q_x[1] = q_x[0] + cap.  Flat pipeline: q_x[0] is ONE array of rec_cap records — the
+    // primary hits at their slot index (< cap), the records of every deeper level densely from index cap on.
+    // General variants: q_x[level & 1], ping-pong by level.
+    float4* q_o[2];         // ray origin  (.w = root = the chain's sample slot, bit-cast)
+    float4* q_d[2];         // ray direction (.w = depth, bit-cast)
+    float4* q_p[2];         // hit point
+    float4* q_n[2];         // hit normal (as intersectMesh returns it)
+    float4* q_t[2];         // texel colour
+    float* targets;         // [rec_cap][3*shadowSamples] light sample positions per record (level 0: reused for the AO directions)
+    unsigned long long* cand;  // [rec_cap] per record: meshes its soft-shadow rays can meet (conservative first pass, once per hit)
+    uint32_t* lit[2];       // [0]: [rec_cap] visible light samples per record; [1]: [cap] occluded AO samples of the primary
+                            // hits (general variants: ping-pong by level parity, [cap] each)
+    float4* stack;          // [cap][stack_stride] level colours of the chain of sample slot r, by depth
+    uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [2] records of levels >= 2, [8 + L] entries of level L >= 1
+                            // ([9] = level-1 records), [last] touched-tile bound exceeded (never, by construction; sticky);
+                            // cleared per pass but for the last
+    uint32_t* hit_rng;      // general variants: per-thread 624-word mt19937 states (long streams)
+    uint32_t cap;           // slot capacity (= samples of the touched tiles of the largest batch)
+    uint32_t tile_slots;    // slots per touched tile: min(tile, width) * min(tile, height) * spp
+    int stack_stride;       // maxBounces + 1 (at least 1)
 };
 
 struct RenderParams {
@@ -67,6 +76,7 @@ struct RenderParams {
     int scene_in_lds;      // 1 when both tables fit the LDS budget (otherwise the kernels read HBM)
     int scene_posed;       // 1 when any mesh has a rotation (selects the kernels that carry the local-frame path)
     int rows_per_batch;    // owned tile rows per pipeline pass
+    int flat;              // 1: flat pipeline (all levels' records shaded at once); 0: general variants, one launch set per level
 };
 
 Shard make_shard(const mcrt_config& cfg, int first, int step);
@@ -75,7 +85,7 @@ Shard make_shard(const mcrt_config& cfg, int first, int step);
 // p.ws.cap / p.ws.stack_stride.  budget_bytes bounds the per-batch workspace (a batch is never
 // smaller than one tile row).
 struct WorkspaceBytes {
-    size_t tile_rng, tile_draws, scol, units, unit_hits, tile_mask, queue_each, targets, cand, lit, stack, counters, hit_rng;
+    size_t tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queue_each, targets, cand, lit0, lit1, stack, counters, hit_rng;
 };
 // row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
 WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);
@@ -87,7 +97,7 @@ constexpr int kCounterWords = 4096;
 // tile size and the shard only — the caller keeps the result across renders and calls this when those change.
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream);
 // enqueue the whole pipeline of one lane on `stream` (p.tile_rng already seeded): per batch of tile rows
-// plan → primary → light_samples, shadow, (ao_dirs, ao,) shade of level 0 → tail (all deeper levels) → resolve
+// plan → primary → bounce → chase → light_samples → shadow → (ao_dirs → ao →) shade → resolve
 hipError_t launch_render(const RenderParams& p, hipStream_t stream);
 
 hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const float* packed, float* frame,

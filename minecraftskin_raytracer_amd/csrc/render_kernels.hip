@@ -16,23 +16,24 @@
 //                                     hit over the tile's mesh mask; misses write their sample colour, hits
 //                                     go to the level-0 queue.  Background tiles: thread per pixel, gradient,
 //                                     ordered sample sum, coalesced float4 / RGBA8 store
-//   level 0 (the primary hits, ~7 % of the samples):
-//     light_samples 1 lane / hit      register-only truncated mt19937 → 2·S draws → the S disk sample
+//   bounce          1 lane / primary hit   reflection ray (geometry only: direction, hit point, normal) → closest
+//                                     hit → level-1 record; chains that end are marked
+//   chase           1 lane / level-1 record        the rest of the chain: reflect, closest hit, append, until the ray
+//                                     misses or maxBounces is reached (~10 % go on per level)
+//   ... then ONCE over the records of ALL levels (550 k + 55 k + 5 k + ... at 1080p / 4 spp):
+//   light_samples   1 lane / record   register-only truncated mt19937 → 2·S draws → the S disk sample
 //                                     positions, and the hit's bundle mask (meshes its shadow rays can meet)
-//     shadow        1 lane / (hit, light sample)   exact any-hit test on the bundle mask → lit count
-//     ao_dirs, ao   (AO on)           hemisphere directions + ball mask per hit; any hit within the radius
-//     shade         1 lane / hit      Blinn-Phong (+AO), reflection ray, closest hit → level-1 queue (~1 % of
-//                                     the hits); ended chains write their sample colour
-//   tail            S lanes / chain   ALL deeper levels in one launch: a group of lanes follows a chain to its end —
-//                                     seeding, its S shadow rays (one per lane, ballot), shade, bounce, closest hit —
-//                                     with the chain in registers; then folds the level colours back to front
-//   (general variants — per-hit RNG streams longer than 227 draws — keep one launch set per level)
-//   resolve         1 lane / pixel    ordered sum of the pixel's sample colours (float addition
-//                                     order is part of the result), coalesced float4 / RGBA8 store
-// Queue entries live in HBM as SoA float4 arrays (ping-pong between levels).  Every unit owns a
-// fixed slot range (its samples); its hits are compacted to the front of that range with an LDS
-// prefix sum and a per-unit count — NO global atomics on the hot path (a returning atomic on one
-// word sustains only ~88 ops/us on this chip; per-wave queue claims made `primary` atomic-bound).
+//   shadow          1 lane / (record, light sample)   exact any-hit test on the bundle mask → lit count
+//   ao_dirs, ao     (AO on, primary hits)  hemisphere directions + ball mask per hit; any hit within the radius
+//   shade           1 lane / record   Blinn-Phong (+AO) → the chain's stack of level colours
+//   resolve         1 lane / pixel    folds each sample's chain back to front, ordered sum of the pixel's sample
+//                                     colours (float addition order is part of the result), coalesced float4 / RGBA8 store
+//   (general variants — per-hit RNG streams longer than 227 draws, or more than kFlatMaxBounces bounces — run
+//   light_samples / shadow / level_shade once per recursion level instead of bounce .. shade)
+// Records live in HBM as SoA float4 arrays.  Every unit owns a fixed slot range (its samples); its
+// primary hits are compacted to the front of that range with an LDS prefix sum and a per-unit count —
+// NO global atomics on the hot path (a returning atomic on one word sustains only ~88 ops/us on this
+// chip; per-wave queue claims made `primary` atomic-bound); deeper records take one atomic per 256.
 // A frame is cut into batches of tile rows so that the worst case (every sample of a touched tile hits) fits.
 // No MFMA: there is no dense contraction anywhere on this path.
 #include "kernels.h"
@@ -314,7 +315,7 @@ __device__ __forceinline__ void plan_tile(const SceneView& sc, const RenderParam
     ws.tile_mask[tile] = mask;
     if (mask == 0ull) return;  // background tile: rendered whole by `primary`, never queued
     const uint32_t spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
-    const uint32_t npix = static_cast<uint32_t>(tg.w) * static_cast<uint32_t>(tg.h);
+    const uint32_t npix = static_cast<uint32_t>(tg.w) * static_cast<uint32_t>(tg.h);  // npix * spp <= ws.tile_slots
     const uint32_t parts = static_cast<uint32_t>(p.parts_per_tile);
     const uint32_t per = (npix + parts - 1u) / parts;
     const uint32_t used = (npix + per - 1u) / per;
@@ -327,7 +328,7 @@ __device__ __forceinline__ void plan_tile(const SceneView& sc, const RenderParam
         return;
     }
     const uint32_t slot0 = atomicAdd(&ws.counters[kCntUnits], used);
-    const uint32_t base = ord * static_cast<uint32_t>(cfg.tile_size) * static_cast<uint32_t>(cfg.tile_size) * spp;
+    const uint32_t base = ord * ws.tile_slots;
     for (uint32_t i = 0; i < used; ++i) {
         const uint32_t a = i * per, b = min(npix, a + per);
         ws.units[slot0 + i] = make_uint4(static_cast<uint32_t>(tile), a, b, base + a * spp);
@@ -423,6 +424,10 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                 else
                     is_hit = true;
                 if (!is_hit) ws.scol[sample_slot] = make_float4(col.r, col.g, col.b, col.a);  // final for misses
+                // 0: the colour is in scol (general variants: `level_shade` puts the hits' colours there too).  Flat
+                // pipeline: `bounce` / `chase` overwrite a hit's word with its chain's end code — unless
+                // maxBounces is 0 and the chain is its primary hit alone.
+                ws.end[sample_slot] = (is_hit && p.flat && cfg.max_bounces == 0) ? 3u : 0u;
             }
             // hits → dense entries at the front of the unit's slot range (no global atomics)
             int total = 0;
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
             }
             unit_hits += static_cast<uint32_t>(total);
         }
-        if (tid == 0) ws.unit_hits[0][u] = unit_hits;
+        if (tid == 0) ws.unit_hits[u] = unit_hits;
     }
 
     // ================= background tiles: nothing can be hit, no ray is needed =================
@@ -471,37 +476,203 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// level kernels.  Level 0 entries sit at the front of each unit's slot range (count per unit, no
-// atomics).  From level 1 on the queue is dense: `shade` appends with ONE workgroup-aggregated
-// atomic per 256-entry block — a few thousand per frame instead of one per wave — because the
-// deeper levels are sparse and a ray has microseconds of dependent latency: they need dense
-// launches to keep enough rays in flight.
+// The recursion of RayTracer::traceRay (raytracer.cpp:82-148) as a FLAT pipeline.  The reflection ray
+// of a hit depends on geometry only — direction, hit point, normal (:133-139) — not on the colour
+// of the hit.  So the chain of hits below a primary hit is chased first (`bounce`: every primary hit's
+// reflection ray; `chase`: the ~10 % that hit again, followed to their end), every hit of every level
+// becoming one *record*; then the expensive stages — light samples, shadow rays, shading — run ONCE over
+// all records of all levels, and `resolve` folds each chain's level colours back to front (:143-147)
+// while it sums the pixel's samples.  One launch set per level cost ~40 us of dependent latency per
+// level whatever it held (550 k, 55 k, 5 k, 500, 50 records at 1080p / 4 spp).
+//
+// Primary hits sit at the front of each unit's slot range (count per unit, no atomics).  Deeper records
+// are appended densely behind index `cap` with ONE workgroup-aggregated atomic per 256-entry block:
+// level 1 by `bounce` (counter kCntDeep1), levels >= 2 by `chase` behind them (kCntDeep2).
+// The general variants (per-hit RNG streams longer than the register engine, or more bounces than
+// the flat record arrays are laid out for) keep one launch set per level with ping-pong queues.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCntDense = 8;  // counters[kCntDense + L] = entries of level L >= 1
+constexpr int kCntDense = 8;              // general variants: counters[kCntDense + L] = entries of level L >= 1
+constexpr int kCntDeep1 = kCntDense + 1;  // flat: level-1 records
+constexpr int kCntDeep2 = 2;              // flat: records of levels >= 2
 
-// Calls body(first_entry, n_valid) for consecutive blocks of up to kBlock entries of `level`;
+// which records a queue kernel walks: flat — every record of the batch; else — the entries of `level`
+struct Scope {
+    int level;
+    int flat;
+    __device__ __forceinline__ bool units() const { return flat || level == 0; }  // records at the front of the units' slot ranges
+    __device__ __forceinline__ bool dense() const { return flat || level > 0; }   // records in the dense queue
+    __device__ __forceinline__ int par() const { return flat ? 0 : (level & 1); }
+};
+__device__ __forceinline__ uint32_t dense_count(const WaveSpace& ws, Scope s) {
+    return s.flat ? ws.counters[kCntDeep1] + ws.counters[kCntDeep2] : ws.counters[kCntDense + s.level];
+}
+__device__ __forceinline__ uint32_t dense_base(const WaveSpace& ws, Scope s) { return s.flat ? ws.cap : 0u; }
+
+// Calls body(first_entry, n_valid) for consecutive blocks of up to kBlock entries of the scope;
 // every thread of the workgroup makes the same calls (collectives inside the body are allowed).
 template <class F>
-__device__ __forceinline__ void for_each_entry_block(const WaveSpace& ws, int level, F&& body) {
-    if (level == 0) {
-        const uint32_t n_units = ws.counters[kCntUnits];
-        for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-            const uint32_t base = ws.units[u].w;
-            const uint32_t count = ws.unit_hits[0][u];
-            for (uint32_t k0 = 0; k0 < count; k0 += kBlock) body(base + k0, min(static_cast<uint32_t>(kBlock), count - k0));
-        }
-    } else {
-        const uint32_t count = ws.counters[kCntDense + level];
-        for (uint32_t k0 = blockIdx.x * kBlock; k0 < count; k0 += gridDim.x * kBlock)
-            body(k0, min(static_cast<uint32_t>(kBlock), count - k0));
+__device__ __forceinline__ void for_each_unit_block(const WaveSpace& ws, F&& body) {
+    const uint32_t n_units = ws.counters[kCntUnits];
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint32_t base = ws.units[u].w;
+        const uint32_t count = ws.unit_hits[u];
+        for (uint32_t k0 = 0; k0 < count; k0 += kBlock) body(base + k0, min(static_cast<uint32_t>(kBlock), count - k0));
     }
 }
+template <class F>
+__device__ __forceinline__ void for_each_dense_block(uint32_t base, uint32_t count, F&& body) {
+    for (uint32_t k0 = blockIdx.x * kBlock; k0 < count; k0 += gridDim.x * kBlock) body(base + k0, min(static_cast<uint32_t>(kBlock), count - k0));
+}
+template <class F>
+__device__ __forceinline__ void for_each_entry_block(const WaveSpace& ws, Scope s, F&& body) {
+    if (s.units()) for_each_unit_block(ws, body);
+    if (s.dense()) for_each_dense_block(dense_base(ws, s), dense_count(ws, s), body);
+}
+// True when this workgroup will get no entry block of the scope: it can leave before it stages the scene
+// tables (a deep level holds a few thousand entries, yet every workgroup of a launch would stage 8.7 KB).
+__device__ __forceinline__ bool no_entry_blocks(const WaveSpace& ws, Scope s) {
+    if (s.units() && blockIdx.x < ws.counters[kCntUnits]) return false;
+    if (s.dense() && static_cast<unsigned long long>(blockIdx.x) * kBlock < dense_count(ws, s)) return false;
+    return true;
+}
 
-// True when this workgroup will get no entry block of `level`: it can leave before it stages the scene
-// tables (a deep level holds a few thousand entries, yet every workgroup of the launch used to stage 8.7 KB).
-__device__ __forceinline__ bool no_entry_blocks(const WaveSpace& ws, int level) {
-    if (level == 0) return blockIdx.x >= ws.counters[kCntUnits];
-    return static_cast<unsigned long long>(blockIdx.x) * kBlock >= ws.counters[kCntDense + level];
+struct Record {
+    Ray ray;
+    Hit hit;
+    uint32_t root;
+    int depth;
+};
+__device__ __forceinline__ Record load_record(const WaveSpace& ws, int par, uint32_t e, bool with_texel) {
+    Record r;
+    const float4 qo = ws.q_o[par][e], qd = ws.q_d[par][e], qp = ws.q_p[par][e], qn = ws.q_n[par][e];
+    r.root = __float_as_uint(qo.w);
+    r.depth = __float_as_int(qd.w);
+    r.ray = Ray{mk(qo.x, qo.y, qo.z), mk(qd.x, qd.y, qd.z)};
+    r.hit.hit = true;
+    r.hit.outer = false;
+    r.hit.t = 0.0f;
+    r.hit.p = mk(qp.x, qp.y, qp.z);
+    r.hit.n = mk(qn.x, qn.y, qn.z);
+    r.hit.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
+    if (with_texel) {
+        const float4 qt = ws.q_t[par][e];
+        r.hit.tex = C4{qt.x, qt.y, qt.z, qt.w};
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t chain_code(int records, bool stopped_at_max) {
+    return (static_cast<uint32_t>(records) << 1) | (stopped_at_max ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bounce: the reflection ray of every primary hit (raytracer.cpp:133-139) and its closest hit →
+// level-1 records; chains that end here get their `end` code.
+// ---------------------------------------------------------------------------------------------
+#ifndef MCRT_BOUNCE_WAVES
+#define MCRT_BOUNCE_WAVES 4
+#endif
+template <int kView>
+__global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void bounce_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    __shared__ int s_wcnt[kBlock / 64];
+    __shared__ uint32_t s_out_base;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const SceneView scg = view_of(scene_blob);
+    const WaveSpace& ws = p.ws;
+    if (blockIdx.x >= ws.counters[kCntUnits]) return;  // before the collective staging
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
+    const int max_b = p.cfg.max_bounces;
+    for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+        bool next_hit = false;
+        Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
+        Hit nhit;
+        nhit.hit = false;
+        uint32_t root = 0;
+        if (threadIdx.x < n) {
+            const Record r = load_record(ws, 0, first + threadIdx.x, false);
+            root = r.root;
+            if (max_b < 1) {
+                ws.end[root] = chain_code(1, true);
+            } else {
+                nray = reflect_ray(r.ray, r.hit);
+                nhit = hit_scene(sc, nray, ~0ull);
+                if (nhit.hit)
+                    next_hit = true;
+                else
+                    ws.end[root] = chain_code(1, false);  // bounced ray missed → flat background (raytracer.cpp:94-102)
+            }
+        }
+        int total = 0;
+        const int rank = block_rank(next_hit, s_wcnt, total);
+        if (total > 0) {  // uniform
+            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep1], static_cast<uint32_t>(total));
+            __syncthreads();
+            if (next_hit) push_entry(ws, 0, ws.cap + s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, 1);
+            __syncthreads();
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// chase: every level-1 record's chain followed to its end, a lane per chain — reflect, closest hit,
+// append the record — until the ray misses or the chain reaches maxBounces.  ~10 % of the lanes go on per
+// turn; the loop is workgroup-uniform (it ends when no lane of the block goes on).
+// ---------------------------------------------------------------------------------------------
+template <int kView>
+__global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void chase_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    __shared__ int s_wcnt[kBlock / 64];
+    __shared__ uint32_t s_out_base;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const SceneView scg = view_of(scene_blob);
+    const WaveSpace& ws = p.ws;
+    const uint32_t count1 = ws.counters[kCntDeep1];
+    if (static_cast<unsigned long long>(blockIdx.x) * kBlock >= count1) return;  // before the collective staging
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
+    const int max_b = p.cfg.max_bounces;
+    const uint32_t deep2_base = ws.cap + count1;  // records of levels >= 2 go behind the level-1 records
+    for_each_dense_block(ws.cap, count1, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+        bool active = threadIdx.x < n;
+        Record r;
+        r.root = 0;
+        r.depth = 1;
+        r.ray = Ray{mk(0, 0, 0), mk(0, 0, 0)};
+        r.hit.p = mk(0, 0, 0);
+        r.hit.n = mk(0, 0, 0);
+        if (active) r = load_record(ws, 0, first + threadIdx.x, false);
+        for (;;) {
+            bool next_hit = false;
+            Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
+            Hit nhit;
+            nhit.hit = false;
+            if (active) {
+                if (r.depth >= max_b) {  // no reflection at the last level
+                    ws.end[r.root] = chain_code(r.depth + 1, true);
+                    active = false;
+                } else {
+                    nray = reflect_ray(r.ray, r.hit);
+                    nhit = hit_scene(sc, nray, ~0ull);
+                    if (nhit.hit) {
+                        next_hit = true;
+                    } else {
+                        ws.end[r.root] = chain_code(r.depth + 1, false);
+                        active = false;
+                    }
+                }
+            }
+            int total = 0;
+            const int rank = block_rank(next_hit, s_wcnt, total);
+            if (total == 0) break;  // uniform: no chain of this block goes on
+            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep2], static_cast<uint32_t>(total));
+            __syncthreads();
+            if (next_hit) {
+                push_entry(ws, 0, deep2_base + s_out_base + static_cast<uint32_t>(rank), nray, nhit, r.root, r.depth + 1);
+                r.ray = nray;
+                r.hit.p = nhit.p;
+                r.hit.n = nhit.n;
+                ++r.depth;
+            }
+            __syncthreads();
+        }
+    });
 }
 
 // The S light sample positions of one hit: mt19937(shadow seed) → 2·S draws → disk samples
@@ -549,20 +720,21 @@ __device__ __forceinline__ void emit_light_samples(const SceneView& sc, const Wa
     write_light_samples<kPosed>(sc, ws, e, P, N, S, rng);
 }
 
-// light_samples: per hit, the 397-step mt19937 seeding recurrence (sequential), then its 2·S
-// draws turned into the S light sample positions.  One hit per lane: thousands of resident waves
+// light_samples: per record, the 397-step mt19937 seeding recurrence (sequential), then its 2·S
+// draws turned into the S light sample positions.  One record per lane: thousands of resident waves
 // hide the integer chain, and the S independent cos/sin/sqrt evaluations of a hit interleave.
 template <bool kGeneral, bool kPosed>
 __global__ __launch_bounds__(kBlock) void light_samples_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
                                                                const int level) {
     const SceneView sc = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
-    const int par = level & 1;
+    const Scope scope{level, p.flat};
+    const int par = scope.par();
     const int S = p.cfg.shadow_samples;
     uint32_t* my_rng = nullptr;
     if constexpr (kGeneral)
         my_rng = ws.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * 624;
-    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+    for_each_entry_block(ws, scope, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (threadIdx.x >= n) return;
         const uint32_t e = first + threadIdx.x;
         const float4 hp = ws.q_p[par][e], hn = ws.q_n[par][e];
@@ -571,13 +743,10 @@ __global__ __launch_bounds__(kBlock) void light_samples_kernel(const uint8_t* __
     });
 }
 
-// shadow: one (hit, light sample) pair per lane
+// shadow: one (record, light sample) pair per lane
 // occupancy targets of the queue kernels (measured: 5 waves/SIMD best for shadow; 6+ spills)
 #ifndef MCRT_SHADOW_WAVES
 #define MCRT_SHADOW_WAVES 5
-#endif
-#ifndef MCRT_SHADE_WAVES
-#define MCRT_SHADE_WAVES 4
 #endif
 template <int kView>
 __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
@@ -585,19 +754,22 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
-    const int par = level & 1;
+    const Scope scope{level, p.flat};
+    const int par = scope.par();
     const int mode = shadow_mode(scg, p.cfg);
     const int S = p.cfg.shadow_samples;
     const uint32_t pairs_per_hit = (mode == SHADOW_SOFT) ? static_cast<uint32_t>(S) : 1u;
     // groups of pairs_per_hit consecutive lanes belong to one hit; when that is a power of two
     // <= 64 the lit count is a ballot + popcount, otherwise atomics on a zeroed counter
     const bool pow2 = (pairs_per_hit & (pairs_per_hit - 1u)) == 0u && pairs_per_hit <= 64u;
-    if (level > 0 && pow2) {  // strides over pairs (below)
-        if (static_cast<unsigned long long>(blockIdx.x) * kBlock >= static_cast<unsigned long long>(ws.counters[kCntDense + level]) * pairs_per_hit) return;
-    } else if (no_entry_blocks(ws, level)) {
-        return;
+    const uint32_t n_dense = scope.dense() ? dense_count(ws, scope) : 0u;
+    {  // leave before the collective staging when this workgroup gets nothing
+        const bool some_units = scope.units() && blockIdx.x < ws.counters[kCntUnits];
+        const unsigned long long dense_items = pow2 ? static_cast<unsigned long long>(n_dense) * pairs_per_hit : n_dense;  // pow2: strided over pairs
+        if (!some_units && static_cast<unsigned long long>(blockIdx.x) * kBlock >= dense_items) return;
     }
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
+    uint32_t* lit = ws.lit[par];
     const V3 lpos = ld3(sc.hdr->light_pos);
     const uint32_t lane = threadIdx.x & 63u;
     // one wave-aligned group of up to 64 consecutive (entry, sample) pairs of the range `first` .. +total
@@ -626,46 +798,49 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
             if (q < total && (lane & (pairs_per_hit - 1u)) == 0u) {
                 const unsigned long long grp =
                     (pairs_per_hit == 64u) ? m : ((m >> lane) & ((1ull << pairs_per_hit) - 1ull));
-                ws.lit[par][e] = static_cast<uint32_t>(__popcll(grp));
+                lit[e] = static_cast<uint32_t>(__popcll(grp));
             }
         } else if (visible) {
-            atomicAdd(&ws.lit[par][e], 1u);
+            atomicAdd(&lit[e], 1u);
         }
     };
-    if (level > 0 && pow2) {
-        // dense queue: stride over PAIRS so that even a sparse level spreads over all workgroups
-        const uint32_t count = ws.counters[kCntDense + level];
-        const unsigned long long total = static_cast<unsigned long long>(count) * pairs_per_hit;
-        const unsigned long long step = static_cast<unsigned long long>(gridDim.x) * kBlock;
-        for (unsigned long long q0 = static_cast<unsigned long long>(blockIdx.x) * kBlock + (threadIdx.x & ~63u); q0 < total; q0 += step) {
-            // 64 consecutive pairs start at entry q0 / pairs_per_hit exactly (pairs_per_hit divides 64)
-            const uint32_t first = static_cast<uint32_t>(q0 / pairs_per_hit);
-            const uint32_t left = static_cast<uint32_t>(min(total - q0, 64ull));
-            trace_pairs(first, 0u, left);
-        }
-        return;
-    }
-    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+    auto entry_block = [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (!pow2) {
-            if (threadIdx.x < n) ws.lit[par][first + threadIdx.x] = 0u;
+            if (threadIdx.x < n) lit[first + threadIdx.x] = 0u;
             __syncthreads();
         }
         const uint32_t total = n * pairs_per_hit;
         // every lane of a wave runs the same number of iterations (ballot inside)
         for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) trace_pairs(first, q0, total);
-    });
+    };
+    if (scope.units()) for_each_unit_block(ws, entry_block);
+    if (!scope.dense()) return;
+    const uint32_t base = dense_base(ws, scope);
+    if (pow2) {
+        // dense queue: stride over PAIRS so that even a sparse queue spreads over all workgroups
+        const unsigned long long total = static_cast<unsigned long long>(n_dense) * pairs_per_hit;
+        const unsigned long long step = static_cast<unsigned long long>(gridDim.x) * kBlock;
+        for (unsigned long long q0 = static_cast<unsigned long long>(blockIdx.x) * kBlock + (threadIdx.x & ~63u); q0 < total; q0 += step) {
+            // 64 consecutive pairs start at entry q0 / pairs_per_hit exactly (pairs_per_hit divides 64)
+            const uint32_t first = base + static_cast<uint32_t>(q0 / pairs_per_hit);
+            const uint32_t left = static_cast<uint32_t>(min(total - q0, 64ull));
+            trace_pairs(first, 0u, left);
+        }
+    } else {
+        for_each_dense_block(base, n_dense, entry_block);
+    }
 }
 
-// ambient occlusion (raytracer.cpp:38-78, depth 0 only) as two stages after the level-0 shadows:
+// ambient occlusion (raytracer.cpp:38-78, depth 0 only) as two stages over the primary hits:
 // ao_dirs — lane per hit: tangent frame, mt19937(ao seed), the A cosine-weighted directions, stored
-// where the (now consumed) light samples of level 0 were; ao — lane per (hit, direction): any hit
-// closer than the radius, counted per hit into lit[1] (free until the level-1 shadows).
+// where the (now consumed) light samples of the primary hits were; ao — lane per (hit, direction): any hit
+// closer than the radius, counted per hit into lit[1].
 template <bool kPosed>
 __global__ __launch_bounds__(kBlock) void ao_dirs_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
     const SceneView sc = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
     const int A = p.cfg.ao_samples;
-    for_each_entry_block(ws, 0, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+    for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (threadIdx.x >= n) return;
         const uint32_t e = first + threadIdx.x;
         const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
@@ -673,7 +848,7 @@ __global__ __launch_bounds__(kBlock) void ao_dirs_kernel(const uint8_t* __restri
         const V3 N = normalize(mk(hn.x, hn.y, hn.z));
         const V3 T = (__builtin_fabsf(N.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), N)) : normalize(cross(mk(0, 1, 0), N));
         const V3 B = cross(N, T);
-        // the meshes any of this hit's AO rays can meet (the level-0 shadow masks are consumed by now)
+        // the meshes any of this hit's AO rays can meet (the primary hits' shadow masks are consumed by now)
         ws.cand[e] = ball_candidates<kPosed>(sc, P + N * 1e-3f, p.cfg.ao_radius);
         MtShort rng;
         rng.seed(ao_seed(P));
@@ -699,14 +874,14 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uin
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
-    if (no_entry_blocks(ws, 0)) return;
+    if (blockIdx.x >= ws.counters[kCntUnits]) return;
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const uint32_t A = static_cast<uint32_t>(p.cfg.ao_samples);
     const float radius = p.cfg.ao_radius;
     const bool pow2 = (A & (A - 1u)) == 0u && A <= 64u;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* occ_out = ws.lit[1];
-    for_each_entry_block(ws, 0, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+    for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (!pow2) {
             if (threadIdx.x < n) occ_out[first + threadIdx.x] = 0u;
             __syncthreads();
@@ -739,20 +914,49 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uin
     });
 }
 
-// shade: colour of the level, reflection ray, closest hit of the next level → survivors to the queue of
-// level + 1.  kGeneral = false: level 0 only — `tail` takes every deeper level, survivors' light samples
-// included.  kGeneral = true (per-hit RNG streams longer than the register engine): one launch per level; the
-// survivors' light samples are produced here, packed.
-template <int kView, bool kGeneral>
-__global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
-                                                       const int level) {
+// shade (flat pipeline): the colour of every record — Blinn-Phong with its visibility term (shading.cpp:62-96),
+// times the AO factor for primary hits (raytracer.cpp:121-130) — onto its chain's stack at the record's depth.
+// Needs no scene tables: no ray is traced here.
+__global__ __launch_bounds__(kBlock) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    const SceneView sc = view_of(scene_blob);
+    const WaveSpace& ws = p.ws;
+    const mcrt_config& cfg = p.cfg;
+    const int mode = shadow_mode(sc, cfg);
+    const int S = cfg.shadow_samples;
+    const int stride = ws.stack_stride;
+    for_each_entry_block(ws, Scope{0, 1}, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+        if (threadIdx.x >= n) return;
+        const uint32_t e = first + threadIdx.x;
+        const Record r = load_record(ws, 0, e, true);
+        const uint32_t lit = ws.lit[0][e];
+        const float vis = (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
+        C4 c = shade(sc, r.hit, normalize(r.ray.o - r.hit.p), vis);
+        if (cfg.ao_enabled && r.depth == 0) {  // raytracer.cpp:121-130; occluded count from the ao stage (e < cap: a primary hit)
+            const float ao = 1.0f - static_cast<float>(ws.lit[1][e]) / static_cast<float>(cfg.ao_samples);
+            const float k = 1.0f - cfg.ao_intensity * (1.0f - ao);
+            c.r *= k;
+            c.g *= k;
+            c.b *= k;
+        }
+        ws.stack[static_cast<size_t>(r.root) * stride + r.depth] = make_float4(c.r, c.g, c.b, c.a);
+    });
+}
+
+// level_shade (general variants): colour of the level, reflection ray, closest hit of the next level →
+// survivors to the queue of level + 1 with their light samples (packed); ended chains fold their level
+// colours back to front and write the sample's colour.
+template <int kView>
+__global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p,
+                                                              const int level) {
+    constexpr bool kGeneral = true;
     __shared__ int s_wcnt[kBlock / 64];
     __shared__ uint32_t s_out_base;
-    __shared__ float4 s_np[kGeneral ? kBlock : 1], s_nn[kGeneral ? kBlock : 1];  // new hits handed to the packed threads
+    __shared__ float4 s_np[kBlock], s_nn[kBlock];  // new hits handed to the packed threads
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
-    if (no_entry_blocks(ws, level)) return;  // before the collective staging
+    const Scope scope{level, 0};
+    if (no_entry_blocks(ws, scope)) return;  // before the collective staging
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const mcrt_config& cfg = p.cfg;
     const int par = level & 1;
@@ -762,9 +966,8 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
     const float* fb = sc.hdr->background;
     const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
     uint32_t* my_rng = nullptr;
-    if constexpr (kGeneral)
-        if (ws.hit_rng) my_rng = ws.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * 624;
-    for_each_entry_block(ws, level, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+    if (ws.hit_rng) my_rng = ws.hit_rng + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * 624;
+    for_each_entry_block(ws, scope, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         bool next_hit = false;
         Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
         Hit nhit;
@@ -773,43 +976,22 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
         int depth = 0;
         if (threadIdx.x < n) {
             const uint32_t e = first + threadIdx.x;
-            const float4 qo = ws.q_o[par][e], qd = ws.q_d[par][e], qp = ws.q_p[par][e], qn = ws.q_n[par][e],
-                         qt = ws.q_t[par][e];
-            root = __float_as_uint(qo.w);
-            depth = __float_as_int(qd.w);
-            const Ray ray{mk(qo.x, qo.y, qo.z), mk(qd.x, qd.y, qd.z)};
-            Hit hit;
-            hit.hit = true;
-            hit.outer = false;
-            hit.t = 0.0f;
-            hit.p = mk(qp.x, qp.y, qp.z);
-            hit.n = mk(qn.x, qn.y, qn.z);
-            hit.tex = C4{qt.x, qt.y, qt.z, qt.w};
+            const Record r = load_record(ws, par, e, true);
+            root = r.root;
+            depth = r.depth;
             const uint32_t lit = ws.lit[par][e];
             const float vis =
                 (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
-            C4 c;
-            if constexpr (kGeneral)
-                c = level_color(sc, cfg, ray.o, hit, depth, vis, my_rng);
-            else {
-                c = shade(sc, hit, normalize(ray.o - hit.p), vis);
-                if (cfg.ao_enabled && level == 0) {  // raytracer.cpp:121-130; occluded count from the ao stage
-                    const float ao = 1.0f - static_cast<float>(ws.lit[1][e]) / static_cast<float>(cfg.ao_samples);
-                    const float k = 1.0f - cfg.ao_intensity * (1.0f - ao);
-                    c.r *= k;
-                    c.g *= k;
-                    c.b *= k;
-                }
-            }
+            const C4 c = level_color(sc, cfg, r.ray.o, r.hit, depth, vis, my_rng);
             bool done = false;
             C4 tail = flat_bg;
             if (depth >= cfg.max_bounces) {  // no reflection: `shadedColor.a = originalAlpha; return clamp()`
                 tail = clamp4(c);
                 done = true;
             } else {
-                nray = reflect_ray(ray, hit);
+                nray = reflect_ray(r.ray, r.hit);
                 nhit = hit_scene(sc, nray, ~0ull);
-                if (nhit.hit) {  // the chain goes on (~1 % of the hits): its level colour waits on the stack for the fold
+                if (nhit.hit) {  // the chain goes on: its level colour waits on the stack for the fold
                     ws.stack[static_cast<size_t>(root) * stride + depth] = make_float4(c.r, c.g, c.b, c.a);
                     next_hit = true;
                 } else {  // bounced ray missed → flat background (raytracer.cpp:94-102), folded in at once (:143-147)
@@ -830,182 +1012,70 @@ __global__ __launch_bounds__(kBlock, kGeneral ? 2 : MCRT_SHADE_WAVES) void shade
         const int rank = block_rank(next_hit, s_wcnt, total);
         if (total > 0) {  // uniform
             if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
-            const bool soft = kGeneral && mode == SHADOW_SOFT;
-            if constexpr (kGeneral) {
-                if (next_hit && soft) {  // hand the new hit to thread `rank`: the survivors' work below runs packed
-                    s_np[rank] = make_float4(nhit.p.x, nhit.p.y, nhit.p.z, __int_as_float(depth + 1));
-                    s_nn[rank] = make_float4(nhit.n.x, nhit.n.y, nhit.n.z, 0.0f);
-                }
+            const bool soft = mode == SHADOW_SOFT;
+            if (next_hit && soft) {  // hand the new hit to thread `rank`: the survivors' work below runs packed
+                s_np[rank] = make_float4(nhit.p.x, nhit.p.y, nhit.p.z, __int_as_float(depth + 1));
+                s_nn[rank] = make_float4(nhit.n.x, nhit.n.y, nhit.n.z, 0.0f);
             }
             __syncthreads();
             if (next_hit) push_entry(ws, par ^ 1, s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, depth + 1);
-            if constexpr (kGeneral) {
-                // The new entries' light samples (seeding chain + S samples) and bundle masks.  Only a few lanes
-                // per wave survive; threads 0 .. total-1 do it instead, so the chain runs in ceil(total / 64) waves.
-                if (soft && static_cast<int>(threadIdx.x) < total) {
-                    const float4 np = s_np[threadIdx.x], nn = s_nn[threadIdx.x];
-                    typename SampleRng<kGeneral>::type rng;
-                    const V3 P = mk(np.x, np.y, np.z);
-                    seed_light_rng<kGeneral>(rng, P, __float_as_int(np.w), S, my_rng);
-                    write_light_samples<kView != kViewLdsUnposed>(scg, ws, s_out_base + threadIdx.x, P, mk(nn.x, nn.y, nn.z), S, rng);
-                }
+            // The new entries' light samples (seeding chain + S samples) and bundle masks.  Only a few lanes
+            // per wave survive; threads 0 .. total-1 do it instead, so the chain runs in ceil(total / 64) waves.
+            if (soft && static_cast<int>(threadIdx.x) < total) {
+                const float4 np = s_np[threadIdx.x], nn = s_nn[threadIdx.x];
+                typename SampleRng<kGeneral>::type rng;
+                const V3 P = mk(np.x, np.y, np.z);
+                seed_light_rng<kGeneral>(rng, P, __float_as_int(np.w), S, my_rng);
+                write_light_samples<kView != kViewLdsUnposed>(scg, ws, s_out_base + threadIdx.x, P, mk(nn.x, nn.y, nn.z), S, rng);
             }
             __syncthreads();
         }
     });
 }
 
-// ---------------------------------------------------------------------------------------------
-// tail: every recursion level below the first bounce, in ONE launch (RayTracer::traceRay's recursion,
-// raytracer.cpp:133-144, for the chains whose first reflection ray hit something: ~1 % of the primary
-// hits, thinning out by another ~100x per level).  Launching light_samples / shadow / shade once per
-// level cost ~40 us per level of pure dependent latency for a few thousand — then a few dozen —
-// entries.  Here a group of G = min(64, pow2 >= S) lanes takes one chain and keeps it in registers to
-// its end: every lane seeds the hit's mt19937 (redundantly: the 397-step chain is sequential, the
-// lanes of a wave run it at the cost of one), lane j skips to draws 2j, 2j+1, forms light sample j
-// and traces shadow ray j; a ballot counts the lit samples; every lane of the group shades,
-// reflects and finds the next closest hit (redundantly again — lane-parallel work is free here,
-// dependent latency is not); lane 0 of the group keeps the level colours on the chain's stack and
-// folds them back to front when the chain ends.  Nothing but the chain's final colour reaches HBM.
-// Hard shadows: G = 1, a lane per chain.
-// ---------------------------------------------------------------------------------------------
-constexpr int kTailGrid = 1024;
-constexpr int kTailFrom = 2;  // first level `tail` takes
-template <int kView>
-__global__ __launch_bounds__(kBlock) void tail_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p, const int start_level) {
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    const SceneView scg = view_of(scene_blob);
-    const WaveSpace& ws = p.ws;
-    const mcrt_config& cfg = p.cfg;
-    const int par = start_level & 1;
-    const uint32_t count = ws.counters[kCntDense + start_level];
-    const int mode = shadow_mode(scg, cfg);
-    const uint32_t S = static_cast<uint32_t>(cfg.shadow_samples);
-    const uint32_t pairs = (mode == SHADOW_SOFT) ? S : 1u;
-    uint32_t G = 1u;
-    while (G < pairs && G < 64u) G <<= 1;
-    const uint32_t chains_per_block = kBlock / G;
-    if (static_cast<unsigned long long>(blockIdx.x) * chains_per_block >= count) return;  // uniform; before the collective staging
-    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
-    constexpr bool kPosed = kView != kViewLdsUnposed;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gl = threadIdx.x & (G - 1u);  // lane within its chain's group
-    const uint32_t gshift = lane - gl;           // the group's first lane within the wave
-    const unsigned long long gmask = (G == 64u) ? ~0ull : ((1ull << G) - 1ull);
-    const uint32_t rounds = (pairs + G - 1u) / G;  // light samples per lane (1 unless S > 64)
-    const V3 lpos = ld3(scg.hdr->light_pos);
-    const float lradius = scg.hdr->light_radius;
-    const int stride = ws.stack_stride;
-    const float* fb = scg.hdr->background;
-    const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
-    const unsigned long long step = static_cast<unsigned long long>(gridDim.x) * chains_per_block;
-    // no workgroup barrier below: the waves of a block advance independently
-    for (unsigned long long c0 = static_cast<unsigned long long>(blockIdx.x) * chains_per_block; c0 < count; c0 += step) {
-        const unsigned long long c = c0 + threadIdx.x / G;
-        bool active = c < count;
-        Ray ray{mk(0, 0, 0), mk(0, 0, 0)};
-        Hit hit;
-        hit.hit = true;
-        hit.outer = false;
-        hit.t = 0.0f;
-        hit.p = mk(0, 0, 0);
-        hit.n = mk(0, 0, 0);
-        hit.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
-        uint32_t root = 0;
-        int depth = start_level;
-        if (active) {  // the entry as `shade` pushed it
-            const float4 qo = ws.q_o[par][c], qd = ws.q_d[par][c], qp = ws.q_p[par][c], qn = ws.q_n[par][c], qt = ws.q_t[par][c];
-            root = __float_as_uint(qo.w);
-            depth = __float_as_int(qd.w);
-            ray = Ray{mk(qo.x, qo.y, qo.z), mk(qd.x, qd.y, qd.z)};
-            hit.p = mk(qp.x, qp.y, qp.z);
-            hit.n = mk(qn.x, qn.y, qn.z);
-            hit.tex = C4{qt.x, qt.y, qt.z, qt.w};
-        }
-        while (__ballot(active) != 0ull) {  // wave-uniform: one level of every live chain of the wave per turn
-            // ---- visibility of the light from the hit (raytracer.cpp:107-115, shading.cpp:28-60)
-            uint32_t lit = 0u;
-            if (mode == SHADOW_SOFT) {
-                MtShort rng;
-                rng.lo = rng.hi = rng.i = 0u;
-                unsigned long long cand = 0ull;
-                LightFrame frame{mk(0, 0, 0), mk(0, 0, 0)};
-                if (active) {
-                    rng.seed(shadow_seed(hit.p, depth));
-                    cand = bundle_candidates<kPosed>(scg, hit.p + hit.n * 1e-3f, lpos, lradius);
-                    frame = light_frame(scg, hit.p);
-                }
-                for (uint32_t r = 0; r < rounds; ++r) {  // uniform trip count
-                    const uint32_t smp = r * G + gl;
-                    bool vis = false;
-                    if (active && smp < S) {
-                        while (rng.i < 2u * smp) rng.skip();  // sample i takes draws 2i, 2i+1 of the hit's stream (shading.cpp:46-47)
-                        const float d0 = rng.uniform();
-                        const float d1 = rng.uniform();
-                        vis = !in_shadow_masked(sc, hit.p, hit.n, light_sample_on_frame(scg, frame, d0, d1), cand);
-                    }
-                    const unsigned long long m = __ballot(vis);
-                    lit += static_cast<uint32_t>(__popcll((m >> gshift) & gmask));
-                }
-            } else if (active) {
-                V3 N = hit.n;
-                if (mode == SHADOW_HARD) N = normalize(N);
-                lit = in_shadow_inline(sc, hit.p, N, lpos) ? 0u : 1u;
-            }
-            // ---- colour of the level, reflection, next closest hit (raytracer.cpp:117-144)
-            if (active) {
-                const float vis =
-                    (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
-                const C4 c = shade(sc, hit, normalize(ray.o - hit.p), vis);
-                bool done = false;
-                C4 tail = flat_bg;
-                if (depth >= cfg.max_bounces) {
-                    tail = clamp4(c);
-                    done = true;
-                } else {
-                    const Ray nray = reflect_ray(ray, hit);
-                    const Hit nhit = hit_scene(sc, nray, ~0ull);
-                    if (nhit.hit) {
-                        if (gl == 0u) ws.stack[static_cast<size_t>(root) * stride + depth] = make_float4(c.r, c.g, c.b, c.a);
-                        ray = nray;
-                        hit = nhit;
-                        ++depth;
-                    } else {
-                        tail = fold_reflection(c, flat_bg);
-                        done = true;
-                    }
-                }
-                if (done) {
-                    if (gl == 0u) {  // the lane that wrote the chain's stack reads it back
-                        for (int d = depth - 1; d >= 0; --d) {
-                            const float4 sd = ws.stack[static_cast<size_t>(root) * stride + d];
-                            tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
-                        }
-                        ws.scol[root] = make_float4(tail.r, tail.g, tail.b, tail.a);
-                    }
-                    active = false;
-                }
-            }
-        }
-    }
-}
-
-// resolve: ordered per-pixel sum of the queued units' sample colours (tile_renderer.cpp:116-124)
-__global__ __launch_bounds__(kBlock) void resolve_kernel(float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p) {
+// resolve: ordered per-pixel sum of the queued units' sample colours (tile_renderer.cpp:116-124).  A
+// sample that started a chain gets its colour here: the chain's level colours folded back to front
+// (raytracer.cpp:143-147) from where the chain ended — the flat background when its last reflection ray
+// missed (:94-102), the clamped last level colour when it stopped at maxBounces (:146-147).
+__global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restrict__ scene_blob, float4* __restrict__ out_frame,
+                                                         uchar4* __restrict__ out8, const RenderParams p) {
     const WaveSpace& ws = p.ws;
     const mcrt_config& cfg = p.cfg;
     const uint32_t n_units = ws.counters[kCntUnits];
     const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const float inv_spp = 1.0f / static_cast<float>(spp);
+    const int stride = ws.stack_stride;
+    const float* fb = view_of(scene_blob).hdr->background;
+    const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint4 d = ws.units[u];
         const TileGeom tg = tile_of(p, static_cast<int>(d.x));
         const uint32_t pp0 = d.y, pp1 = d.z;
         for (uint32_t i = pp0 + threadIdx.x; i < pp1; i += kBlock) {
-            const float4* src = ws.scol + d.w + static_cast<size_t>(i - pp0) * spp;
+            const uint32_t slot0 = d.w + (i - pp0) * static_cast<uint32_t>(spp);
             float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             for (int s = 0; s < spp; ++s) {
-                const float4 c = src[s];
+                const uint32_t slot = slot0 + static_cast<uint32_t>(s);
+                const uint32_t code = ws.end[slot];
+                float4 c;
+                if (code == 0u) {
+                    c = ws.scol[slot];
+                } else {
+                    const float4* lv = ws.stack + static_cast<size_t>(slot) * stride;
+                    const int records = static_cast<int>(code >> 1);
+                    C4 tail = flat_bg;
+                    int dd = records - 1;
+                    if (code & 1u) {
+                        const float4 last = lv[dd];
+                        tail = clamp4(C4{last.x, last.y, last.z, last.w});
+                        --dd;
+                    }
+                    for (; dd >= 0; --dd) {
+                        const float4 sd = lv[dd];
+                        tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
+                    }
+                    c = make_float4(tail.r, tail.g, tail.b, tail.a);
+                }
                 acc.x += c.x;
                 acc.y += c.y;
                 acc.z += c.z;
@@ -1147,10 +1217,15 @@ Shard make_shard(const mcrt_config& cfg, int first, int step) {
 static int owned_tiles(const RenderParams& p) { return p.shard.owned_rows * p.shard.tiles_x; }
 static bool soft_sampling(const mcrt_config& c) { return c.soft_shadows && c.shadow_samples > 1; }
 
-// rare feature that needs the general kernel variants: per-hit RNG streams longer than the
-// register-only engine covers (they run AO inside `shade`, sequentially)
+// The flat pipeline keeps the records of every level at once: its arrays are laid out for up to
+// kFlatMaxBounces reflection levels (1 + maxBounces records per sample slot in the worst case).
+constexpr int kFlatMaxBounces = 8;
+// rare features that need the general kernel variants (one launch set per level, ping-pong queues): per-hit RNG
+// streams longer than the register-only engine covers (they run AO inside `level_shade`, sequentially), or
+// more bounces than the flat record arrays are laid out for
 static bool needs_general_variant(const mcrt_config& c) {
-    return (c.ao_enabled && (c.ao_samples <= 0 || 2 * c.ao_samples > kMtShortMax)) || (soft_sampling(c) && 2 * c.shadow_samples > kMtShortMax);
+    return (c.ao_enabled && (c.ao_samples <= 0 || 2 * c.ao_samples > kMtShortMax)) || (soft_sampling(c) && 2 * c.shadow_samples > kMtShortMax) ||
+           c.max_bounces > kFlatMaxBounces;
 }
 
 // Parts of a tile that meshes can touch: one 256-sample chunk each, at most 16 — fine enough that
@@ -1170,15 +1245,20 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     const mcrt_config& c = p.cfg;
     const int n_tiles = owned_tiles(p);
     p.parts_per_tile = choose_parts_per_tile(c);
-    p.ws.stack_stride = c.max_bounces > 1 ? c.max_bounces : 1;
+    p.flat = needs_general_variant(c) ? 0 : 1;
+    p.ws.stack_stride = c.max_bounces > 0 ? c.max_bounces + 1 : 1;
     const size_t spp = c.samples_per_pixel > 1 ? c.samples_per_pixel : 1;
-    // every tile that meshes can touch owns tile_size^2 * spp slots (clipped edge tiles included)
-    const size_t tile_slots = static_cast<size_t>(c.tile_size) * c.tile_size * spp;
+    // every tile that meshes can touch owns one slot per sample of a full (frame-clipped) tile
+    const size_t tile_w = static_cast<size_t>(c.tile_size < c.width ? c.tile_size : c.width);
+    const size_t tile_h = static_cast<size_t>(c.tile_size < c.height ? c.tile_size : c.height);
+    const size_t tile_slots = tile_w * tile_h * spp;
     const size_t S = soft_sampling(c) ? static_cast<size_t>(c.shadow_samples) : 0;
-    // bytes per potential hit: colour slot, 2 x 5 queue arrays, draws, lit, stack, root_sample
     const size_t A = c.ao_enabled && c.ao_samples > 0 ? static_cast<size_t>(c.ao_samples) : 0;
     const size_t rays = S > A ? S : A;  // light samples and AO directions share one array
-    const size_t per_entry = 16 + 2 * 5 * 16 + 12 * rays + (rays ? 8 : 0) + 2 * 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
+    // records per slot: flat — the primary hit and one per reflection level; general — two ping-pong queues
+    const size_t recs = p.flat ? static_cast<size_t>(1 + (c.max_bounces > 0 ? c.max_bounces : 0)) : 2;
+    // bytes per slot: colour + end code, per record 5 float4 + light samples + mask + lit, AO counts, stack
+    const size_t per_entry = 16 + 4 + recs * (5 * 16 + 12 * rays + (rays ? 8 : 0) + 4) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
     const int owned = p.shard.owned_rows;
     auto row_count = [&](int j) -> size_t { return row_touched ? static_cast<size_t>(row_touched[j]) : static_cast<size_t>(p.shard.tiles_x); };
     // touched tiles of the fullest batch when the shard is cut into batches of R owned rows
@@ -1191,13 +1271,15 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
         }
         return mx;
     };
-    // every tile of a batch (touched or not) also holds its jitter / lens draws: tile_size^2 * spp * draws floats
-    const size_t draws_stride = static_cast<size_t>(c.tile_size) * c.tile_size * spp * static_cast<size_t>(p.draws_per_sample);
+    // every tile of a batch (touched or not) also holds its jitter / lens draws
+    const size_t draws_stride = tile_slots * static_cast<size_t>(p.draws_per_sample);
     const size_t draws_row_bytes = draws_stride * 4 * static_cast<size_t>(p.shard.tiles_x);
     p.ws.draws_stride = static_cast<uint32_t>(draws_stride > 0xffffffffull ? 0xffffffffull : draws_stride);
-    // slots are indexed with 32 bits (with room for the 3·S / stack multipliers done in size_t)
+    p.ws.tile_slots = static_cast<uint32_t>(tile_slots > 0xffffffffull ? 0xffffffffull : tile_slots);
+    // records are indexed with 32 bits (with room for the 3·S multiplier done in size_t)
+    const size_t index_limit = 0x7ffffff0ull / recs;
     size_t tile_budget = budget_bytes / (per_entry * (tile_slots ? tile_slots : 1));
-    if (tile_slots && tile_budget > 0x7ffffff0ull / tile_slots) tile_budget = 0x7ffffff0ull / tile_slots;
+    if (tile_slots && tile_budget > index_limit / tile_slots) tile_budget = index_limit / tile_slots;
     int rows = owned > 0 ? owned : 1;
     // a batch of R rows fits when its hit workspace and its draws fit the budget together
     auto fits = [&](int R) -> bool {
@@ -1216,67 +1298,63 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     size_t cap_tiles = owned > 0 ? fullest(rows) : 0;
     if (cap_tiles < 1) cap_tiles = 1;
     p.rows_per_batch = rows;
-    if (tile_slots == 0 || cap_tiles > 0x7ffffff0ull / tile_slots || draws_stride > 0xfffffff0ull)
+    if (tile_slots == 0 || cap_tiles > index_limit / tile_slots || draws_stride > 0xfffffff0ull)
         p.rows_per_batch = 0;  // one tile (row) alone exceeds the 32-bit index ranges: refused by the caller
-    const size_t cap = cap_tiles * tile_slots;
-    p.ws.cap = static_cast<uint32_t>(cap > 0xfffffff0ull ? 0xfffffff0ull : cap);
+    const size_t cap = p.rows_per_batch ? cap_tiles * tile_slots : 1;
+    const size_t rec_cap = cap * recs;
+    p.ws.cap = static_cast<uint32_t>(cap);
     p.ws.tile_cap = static_cast<uint32_t>(cap_tiles);
     w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 : 0;
     w.tile_draws = static_cast<size_t>(rows) * draws_row_bytes;
     w.scol = cap * 16;
+    w.end = cap * 4;
     p.ws.unit_cap = static_cast<uint32_t>(cap_tiles * static_cast<size_t>(p.parts_per_tile));
     w.units = static_cast<size_t>(p.ws.unit_cap) * 16;
     w.unit_hits = static_cast<size_t>(p.ws.unit_cap) * 4;
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
-    w.queue_each = cap * 16;
-    w.targets = cap * 12 * rays;
-    w.cand = rays ? cap * 8 : 0;
-    w.lit = cap * 4;
+    w.queue_each = rec_cap * 16;
+    w.targets = rec_cap * 12 * rays;
+    w.cand = rays ? rec_cap * 8 : 0;
+    w.lit0 = (p.flat ? rec_cap : cap) * 4;
+    w.lit1 = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
     w.counters = static_cast<size_t>(kCounterWords) * 4;
-    w.hit_rng = needs_general_variant(c) ? static_cast<size_t>(256) * kBlock * 624 * 4 : 0;  // general grids are capped at 256 WGs
+    w.hit_rng = p.flat ? 0 : static_cast<size_t>(256) * kBlock * 624 * 4;  // general grids are capped at 256 WGs
     return w;
 }
 
 template <int kView>
 static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn) {
     const mcrt_config& c = p.cfg;
-    const bool general = needs_general_variant(c);
     const bool soft = soft_sampling(c);
     const int levels = c.max_bounces < 0 ? 0 : c.max_bounces + 1;
-    static const int tuned_grid = [] {  // development knob
+    if (levels < 1) return;
+    constexpr bool posed = kView != kViewLdsUnposed;
+    if (!p.flat) {  // general variants: one launch set per level; `level_shade` emits the light samples of the entries it appends
+        const int grid = 256;
+        for (int L = 0; L < levels; ++L) {
+            if (soft && L == 0) hipLaunchKernelGGL((light_samples_kernel<true, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
+            hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+            hipLaunchKernelGGL(level_shade_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+        }
+        return;
+    }
+    static const int grid = [] {  // development knob
         const char* e = getenv("MCRT_QUEUE_GRID");
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : kQueueGrid;
     }();
-    const int grid = general ? 256 : tuned_grid;
-    constexpr bool posed = kView != kViewLdsUnposed;
-    if (general) {  // one launch set per level; `shade` emits the light samples of the entries it appends
-        for (int L = 0; L < levels; ++L) {
-            if (soft && L == 0) hipLaunchKernelGGL((light_samples_kernel<true, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
-            hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
-            hipLaunchKernelGGL((shade_kernel<kView, true>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
-        }
-        return;
+    if (levels >= 2) {  // the chains below the primary hits (maxBounces = 0: `primary` has marked them already)
+        hipLaunchKernelGGL(bounce_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
+        hipLaunchKernelGGL(chase_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    // Levels 0 and 1 are dense enough for lane-efficient stages (a 64x64 skin with its outer layer: ~7 % of the
-    // samples hit, ~10 % of the reflection rays hit again — 550 k, 55 k, 5 k, ... entries at 1080p / 4 spp); from
-    // level kTailFrom on, one `tail` launch follows every remaining chain to its end.
-    static const int tail_from = [] {  // development knob
-        const char* e = getenv("MCRT_TAIL_FROM");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : kTailFrom;
-    }();
-    for (int L = 0; L < levels && L < tail_from; ++L) {
-        if (soft) hipLaunchKernelGGL((light_samples_kernel<false, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, L);
-        hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
-        if (L == 0 && c.ao_enabled && c.ao_samples > 0) {
-            hipLaunchKernelGGL(ao_dirs_kernel<posed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
-            hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
-        }
-        hipLaunchKernelGGL((shade_kernel<kView, false>), dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, L);
+    if (soft) hipLaunchKernelGGL((light_samples_kernel<false, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, 0);
+    hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, 0);
+    if (c.ao_enabled && c.ao_samples > 0) {
+        hipLaunchKernelGGL(ao_dirs_kernel<posed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
+        hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    if (levels > tail_from) hipLaunchKernelGGL(tail_kernel<kView>, dim3(kTailGrid), dim3(kBlock), dyn, stream, p.scene, p, tail_from);
+    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
 }
 
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
@@ -1316,7 +1394,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
             launch_levels<kViewHbm>(p, stream, 0);
         }
         const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
-        hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, out, out8, p);
+        hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, p.scene, out, out8, p);
     }
     return hipGetLastError();
 }
