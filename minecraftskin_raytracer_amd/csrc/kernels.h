@@ -33,7 +33,7 @@ struct WaveSpace {
     uint4* units;           // units of the tiles meshes can touch: {owned tile, first pixel, end pixel, slot base}
     uint32_t* unit_hits;    // per unit: its primary hits (their records sit at the front of the unit's slot range)
     unsigned long long* tile_mask;  // per owned tile: meshes whose screen bound touches it
-    float* tile_draws;      // [tiles of the batch][draws_stride] every draw of a tile's mt19937 stream, as uniform floats
+    float* tile_draws;      // [touched tiles (bg_in_plan) or all tiles of the batch][draws_stride] a tile's mt19937 draws, as uniform floats
     uint32_t draws_stride;  // tile slots * draws_per_sample
     uint32_t unit_cap;      // capacity of `units`
     uint32_t tile_cap;      // tiles of a batch that may be touched by meshes (host-side superset of the device's culling):
@@ -76,6 +76,8 @@ struct RenderParams {
     int scene_in_lds;      // 1 when both tables fit the LDS budget (otherwise the kernels read HBM)
     int scene_posed;       // 1 when any mesh has a rotation (selects the kernels that carry the local-frame path)
     int rows_per_batch;    // owned tile rows per pipeline pass
+    int bg_in_plan;        // 1: `plan_tiles` renders the background tiles from the draws in LDS and only touched tiles' draws
+                           //    go to HBM; 0 (a pixel's draws exceed one mt19937 twist): all streams to HBM, `primary` renders them
     int flat;              // 1: flat pipeline (all levels' records shaded at once); 0: general variants, one launch set per level
 };
 

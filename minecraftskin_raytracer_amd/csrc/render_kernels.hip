@@ -88,21 +88,83 @@ __global__ __launch_bounds__(64) void seed_tiles_kernel(RenderParams p, int n_ti
 }
 
 // ---------------------------------------------------------------------------------------------
+// pixel store: the float4 frame and/or its RGBA8 quantisation `(u8)(clamp(c,0,1)*255+0.5)`
+// (image_writer.cpp:18-22 ≡ image.cpp:31-36) — the epilogue of `primary` (background tiles) and `resolve`
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uchar4 quantize_pixel(float4 c) {
+    uchar4 q;
+    q.x = static_cast<unsigned char>(sclamp(c.x, 0.0f, 1.0f) * 255.0f + 0.5f);
+    q.y = static_cast<unsigned char>(sclamp(c.y, 0.0f, 1.0f) * 255.0f + 0.5f);
+    q.z = static_cast<unsigned char>(sclamp(c.z, 0.0f, 1.0f) * 255.0f + 0.5f);
+    q.w = static_cast<unsigned char>(sclamp(c.w, 0.0f, 1.0f) * 255.0f + 0.5f);
+    return q;
+}
+__device__ __forceinline__ void store_pixel(float4* __restrict__ out_frame, uchar4* __restrict__ out8, size_t idx, float4 v) {
+    if (out_frame) out_frame[idx] = v;
+    if (out8) out8[idx] = quantize_pixel(v);
+}
+
+// ---------------------------------------------------------------------------------------------
 // tile_streams: every draw renderTile takes from a tile's mt19937 (tile_renderer.cpp:78-99: per pixel
-// in row-major order, per sample, 2 jitter draws if spp > 1, then 2 lens draws if DOF is on), as
-// uniform floats in HBM.  One WAVE per tile: the engine's twist runs inside the wave on a
-// ping-pong state in LDS — LDS operations of one wave are ordered, a wave barrier keeps the
-// compiler from moving them — so there is no workgroup barrier anywhere and all tiles of a batch
-// advance in parallel.  (Generating the stream inside `primary` with block-wide twists made that
-// kernel barrier-bound: 3 barriers per 624 draws, ~60 us of the 1080p / 4 spp frame, milliseconds
-// at 64 spp; units that start mid-tile also had to re-run the twists before their first draw.)
+// in row-major order, per sample, 2 jitter draws if spp > 1, then 2 lens draws if DOF is on).  One
+// WAVE per tile: the engine's twist runs inside the wave on a ping-pong state in LDS — LDS
+// operations of one wave are ordered, a wave barrier keeps the compiler from moving them — so
+// there is no workgroup barrier anywhere and all tiles of a batch advance in parallel.
+//  * A tile that meshes can touch: the draws go to HBM as uniform floats, for `primary`.
+//  * A background tile (93 % of the tiles of the metric frame): nothing can be hit, no ray is needed —
+//    the wave renders the tile itself, straight from the draws in LDS: after each twist the pixels whose
+//    draws are complete (they lie in the new 624 words and the previous 624, both still in LDS) get
+//    their gradient samples, the ordered sample sum (tile_renderer.cpp:111-124) and a coalesced store.
+//    Writing those streams out and reading them back in `primary` was 134 MB of the frame's HBM traffic.
+//    Needs a pixel's draws to fit one twist (spp * draws per sample <= 624: RenderParams::bg_in_plan);
+//    otherwise every tile's stream goes to HBM and `primary` renders the background tiles.
+// (Generating the stream inside `primary` with block-wide twists made that kernel barrier-bound: 3
+// barriers per 624 draws, ~60 us of the 1080p / 4 spp frame, milliseconds at 64 spp.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kStreamWaves = 4;  // tiles per workgroup
-// executed by one wave; `st` = its 2 x 624 words of LDS; `t` = the tile's index within the batch
-__device__ __forceinline__ void tile_stream_wave(const uint32_t* __restrict__ tile_rng, float* __restrict__ tile_draws,
-                                                 const RenderParams& p, const TileGeom& tg, int tile, int t, uint32_t* st, int lane) {
+// the pixels [lo, hi) of a background tile; draw(g) = draw number g of the tile's stream
+template <class DrawFn>
+__device__ __forceinline__ void background_pixels(const SceneView& sc, const RenderParams& p, const TileGeom& tg, float4* __restrict__ out_frame,
+                                                  uchar4* __restrict__ out8, unsigned lo, unsigned hi, int lane, DrawFn&& draw) {
+    const mcrt_config& cfg = p.cfg;
+    const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
+    const unsigned dd = static_cast<unsigned>(p.draws_per_sample);
+    const float fW = static_cast<float>(cfg.width), fH = static_cast<float>(cfg.height);
+    const float inv_spp = 1.0f / static_cast<float>(spp);
+    for (unsigned pix = lo + static_cast<unsigned>(lane); pix < hi; pix += 64u) {
+        const unsigned uly = pix / static_cast<unsigned>(tg.w);
+        const int ly = static_cast<int>(uly);
+        const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
+        const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
+        const unsigned long long g0 = static_cast<unsigned long long>(pix) * static_cast<unsigned>(spp) * dd;
+        float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
+        for (int sidx = 0; sidx < spp; ++sidx) {
+            float jx = 0.5f, jy = 0.5f;
+            if (spp > 1) {
+                jx = draw(g0 + static_cast<unsigned>(sidx) * dd);
+                jy = draw(g0 + static_cast<unsigned>(sidx) * dd + 1u);
+            }
+            const C4 c = background(sc, cfg, (fx + jx) / fW, (fy + jy) / fH);  // tile_renderer.cpp:111-114
+            ar += c.r;
+            ag += c.g;
+            ab += c.b;
+            aa += c.a;
+        }
+        const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
+        store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
+                    make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp));
+    }
+}
+
+// executed by one wave; `st` = its 2 x 624 words of LDS.  dst != nullptr: the tile's draws go there;
+// dst == nullptr: a background tile, rendered from the draws in LDS.
+__device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint32_t* __restrict__ tile_rng, float* __restrict__ dst,
+                                                 float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams& p,
+                                                 const TileGeom& tg, int tile, uint32_t* st, int lane) {
     const int spp = p.cfg.samples_per_pixel > 1 ? p.cfg.samples_per_pixel : 1;
-    const unsigned long long total = static_cast<unsigned long long>(tg.w) * tg.h * spp * p.draws_per_sample;
+    const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
+    const unsigned long long per_pixel = static_cast<unsigned long long>(spp) * p.draws_per_sample;
+    const unsigned long long total = npix * per_pixel;
     const uint32_t* src = tile_rng + static_cast<size_t>(tile) * 624;
     for (int e = lane; e < 624; e += 64) st[e] = src[e];
     auto wave_sync = [&]() __attribute__((always_inline)) {
@@ -110,8 +172,8 @@ __device__ __forceinline__ void tile_stream_wave(const uint32_t* __restrict__ ti
         __builtin_amdgcn_wave_barrier();
     };
     wave_sync();
-    float* dst = tile_draws + static_cast<size_t>(t) * p.ws.draws_stride;
     int cur = 0;
+    unsigned pixels_done = 0;
     for (unsigned long long done = 0; done < total; done += 624) {
         const uint32_t* o = st + cur * 624;
         uint32_t* n = st + (cur ^ 1) * 624;
@@ -138,29 +200,23 @@ __device__ __forceinline__ void tile_stream_wave(const uint32_t* __restrict__ ti
         cur ^= 1;
         const unsigned long long left = total - done;
         const int m = left < 624ull ? static_cast<int>(left) : 624;
+        if (dst) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int e = lane + 64 * i;
-            if (e < m) dst[done + e] = mt_to_unit(mt_temper(n[e]));
+            for (int i = 0; i < 10; ++i) {
+                const int e = lane + 64 * i;
+                if (e < m) dst[done + e] = mt_to_unit(mt_temper(n[e]));
+            }
+        } else {
+            // draws [done, done + m) are in n, the 624 before them in o (the previous twist's words)
+            const unsigned complete = static_cast<unsigned>((done + static_cast<unsigned long long>(m)) / per_pixel);
+            background_pixels(sc, p, tg, out_frame, out8, pixels_done, complete, lane, [&](unsigned long long g) __attribute__((always_inline)) {
+                const uint32_t raw = (g >= done) ? n[g - done] : o[g + 624ull - done];
+                return mt_to_unit(mt_temper(raw));
+            });
+            pixels_done = complete;
+            wave_sync();  // the next twist overwrites o
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pixel store: the float4 frame and/or its RGBA8 quantisation `(u8)(clamp(c,0,1)*255+0.5)`
-// (image_writer.cpp:18-22 ≡ image.cpp:31-36) — the epilogue of `primary` (background tiles) and `resolve`
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uchar4 quantize_pixel(float4 c) {
-    uchar4 q;
-    q.x = static_cast<unsigned char>(sclamp(c.x, 0.0f, 1.0f) * 255.0f + 0.5f);
-    q.y = static_cast<unsigned char>(sclamp(c.y, 0.0f, 1.0f) * 255.0f + 0.5f);
-    q.z = static_cast<unsigned char>(sclamp(c.z, 0.0f, 1.0f) * 255.0f + 0.5f);
-    q.w = static_cast<unsigned char>(sclamp(c.w, 0.0f, 1.0f) * 255.0f + 0.5f);
-    return q;
-}
-__device__ __forceinline__ void store_pixel(float4* __restrict__ out_frame, uchar4* __restrict__ out8, size_t idx, float4 v) {
-    if (out_frame) out_frame[idx] = v;
-    if (out8) out8[idx] = quantize_pixel(v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,7 +337,12 @@ __device__ __forceinline__ void push_entry(const WaveSpace& ws, int parity, uint
 // plan_tiles: one wave per tile of the batch — which meshes can touch the tile, its units and slot
 // range (plan_tile), then the tile's draws (tile_stream_wave)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void plan_tile(const SceneView& sc, const RenderParams& p, const TileGeom& tg, int tile, int lane) {
+__device__ __forceinline__ uint32_t plan_touched_tile(const RenderParams& p, const TileGeom& tg, int tile, unsigned long long mask);
+struct TilePlan {
+    unsigned long long mask;  // meshes whose screen bound touches the tile (0: a background tile)
+    uint32_t ord;             // the tile's number among the batch's touched tiles (~0u: none)
+};
+__device__ __forceinline__ TilePlan plan_tile(const SceneView& sc, const RenderParams& p, const TileGeom& tg, int tile, int lane) {
     const mcrt_config& cfg = p.cfg;
     const WaveSpace& ws = p.ws;
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
@@ -311,9 +372,17 @@ __device__ __forceinline__ void plan_tile(const SceneView& sc, const RenderParam
     }
     unsigned long long mask = __ballot(touch);
     if (!cull && sc.n_meshes > 0) mask = ~0ull;
-    if (lane != 0) return;
+    uint32_t ord = ~0u;
+    if (lane == 0) ord = plan_touched_tile(p, tg, tile, mask);
+    return TilePlan{mask, static_cast<uint32_t>(__shfl(static_cast<int>(ord), 0))};
+}
+// lane 0 of the tile's wave: units and slot range of a tile that meshes can touch; returns its number
+// among the batch's touched tiles
+__device__ __forceinline__ uint32_t plan_touched_tile(const RenderParams& p, const TileGeom& tg, int tile, unsigned long long mask) {
+    const mcrt_config& cfg = p.cfg;
+    const WaveSpace& ws = p.ws;
     ws.tile_mask[tile] = mask;
-    if (mask == 0ull) return;  // background tile: rendered whole by `primary`, never queued
+    if (mask == 0ull) return ~0u;  // background tile: never queued
     const uint32_t spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const uint32_t npix = static_cast<uint32_t>(tg.w) * static_cast<uint32_t>(tg.h);  // npix * spp <= ws.tile_slots
     const uint32_t parts = static_cast<uint32_t>(p.parts_per_tile);
@@ -325,7 +394,7 @@ __device__ __forceinline__ void plan_tile(const SceneView& sc, const RenderParam
     if (ord >= ws.tile_cap) {  // cannot happen; keep memory safe and leave a mark if it ever does
         ws.counters[kCntOverflow] = 1u;
         ws.tile_mask[tile] = 0ull;
-        return;
+        return ~0u;
     }
     const uint32_t slot0 = atomicAdd(&ws.counters[kCntUnits], used);
     const uint32_t base = ord * ws.tile_slots;
@@ -333,11 +402,13 @@ __device__ __forceinline__ void plan_tile(const SceneView& sc, const RenderParam
         const uint32_t a = i * per, b = min(npix, a + per);
         ws.units[slot0 + i] = make_uint4(static_cast<uint32_t>(tile), a, b, base + a * spp);
     }
+    return ord;
 }
 
 __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uint8_t* __restrict__ scene_blob,
                                                                        const uint32_t* __restrict__ tile_rng,
-                                                                       float* __restrict__ tile_draws, const RenderParams p,
+                                                                       float* __restrict__ tile_draws, float4* __restrict__ out_frame,
+                                                                       uchar4* __restrict__ out8, const RenderParams p,
                                                                        const int tile_base, const int n_tiles) {
     __shared__ uint32_t s_state[kStreamWaves][2 * 624];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -345,8 +416,20 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
     if (t >= n_tiles) return;  // wave-uniform; there is no workgroup barrier in this kernel
     const int tile = tile_base + t;
     const TileGeom tg = tile_of(p, tile);
-    plan_tile(view_of(scene_blob), p, tg, tile, lane);
-    if (p.draws_per_sample > 0) tile_stream_wave(tile_rng, tile_draws, p, tg, tile, t, s_state[wave], lane);
+    const SceneView sc = view_of(scene_blob);
+    const TilePlan plan = plan_tile(sc, p, tg, tile, lane);
+    const size_t stride = p.ws.draws_stride;
+    if (!p.bg_in_plan) {  // every tile's draws to HBM; `primary` renders the background tiles
+        if (p.draws_per_sample > 0) tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(t) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
+    } else if (plan.mask != 0ull) {  // a tile meshes can touch: its draws, at its touched-tile number
+        if (p.draws_per_sample > 0 && plan.ord != ~0u)
+            tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(plan.ord) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
+    } else if (p.cfg.samples_per_pixel > 1) {  // background tile, jittered samples
+        tile_stream_wave(sc, tile_rng, nullptr, out_frame, out8, p, tg, tile, s_state[wave], lane);
+    } else {  // background tile, one centred sample per pixel: no draws at all
+        background_pixels(sc, p, tg, out_frame, out8, 0u, static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h), lane,
+                          [](unsigned long long) __attribute__((always_inline)) { return 0.5f; });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -362,9 +445,11 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
     extern __shared__ __align__(16) unsigned char s_dyn[];
 
     const SceneView scg = view_of(scene_blob);
-    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const mcrt_config& cfg = p.cfg;
     const WaveSpace& ws = p.ws;
+    const uint32_t n_units = ws.counters[kCntUnits];
+    if (p.bg_in_plan && blockIdx.x >= n_units) return;  // nothing for this workgroup: leave before the collective staging
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const int tid = threadIdx.x;
     const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const int dd = p.draws_per_sample;
@@ -374,7 +459,6 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
     float focusDist = cfg.focus_distance;
     if (focusDist <= 0.0f) focusDist = sc.hdr->cam_focus_auto;
     const float inv_spp = 1.0f / static_cast<float>(spp);
-    const uint32_t n_units = ws.counters[kCntUnits];
     const size_t stride = ws.draws_stride;
 
     // ================= units of tiles that meshes can touch: thread per sample =================
@@ -385,7 +469,8 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
         const uint32_t slot_base = ud.w;
         const TileGeom tg = tile_of(p, tile);
         const unsigned long long mesh_mask = ws.tile_mask[tile];
-        const float* draws = tile_draws + static_cast<size_t>(tile - tile_base) * stride;
+        // the tile's draws: at its touched-tile number, or (all tiles' streams in HBM) at its index in the batch
+        const float* draws = tile_draws + static_cast<size_t>(p.bg_in_plan ? slot_base / ws.tile_slots : static_cast<uint32_t>(tile - tile_base)) * stride;
         const unsigned n_samples = (pp1 - pp0) * static_cast<unsigned>(spp);
 
         uint32_t unit_hits = 0;  // hits so far: they occupy slots slot_base .. slot_base + unit_hits
@@ -442,7 +527,9 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
     }
 
     // ================= background tiles: nothing can be hit, no ray is needed =================
+    // (only when a pixel's draws exceed one twist — otherwise `plan_tiles` has rendered them from LDS)
     // thread per pixel, its samples in order as renderTile sums them (tile_renderer.cpp:116-124); no barriers
+    if (p.bg_in_plan) return;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int tile = tile_base + t;
         if (ws.tile_mask[tile] != 0ull) continue;  // uniform
@@ -1037,56 +1124,73 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
 // sample that started a chain gets its colour here: the chain's level colours folded back to front
 // (raytracer.cpp:143-147) from where the chain ended — the flat background when its last reflection ray
 // missed (:94-102), the clamped last level colour when it stopped at maxBounces (:146-147).
+// A thread per SAMPLE fetches / folds the colour; the pixel's samples meet in LDS and one thread per
+// pixel adds them in order (float addition order is part of the result).
+__device__ __forceinline__ float4 sample_colour(const WaveSpace& ws, uint32_t slot, int stride, const C4& flat_bg) {
+    const uint32_t code = ws.end[slot];
+    if (code == 0u) return ws.scol[slot];
+    const float4* lv = ws.stack + static_cast<size_t>(slot) * stride;
+    C4 tail = flat_bg;
+    int dd = static_cast<int>(code >> 1) - 1;  // the chain's last record
+    if (code & 1u) {
+        const float4 last = lv[dd];
+        tail = clamp4(C4{last.x, last.y, last.z, last.w});
+        --dd;
+    }
+    for (; dd >= 0; --dd) {
+        const float4 sd = lv[dd];
+        tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
+    }
+    return make_float4(tail.r, tail.g, tail.b, tail.a);
+}
 __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restrict__ scene_blob, float4* __restrict__ out_frame,
                                                          uchar4* __restrict__ out8, const RenderParams p) {
+    __shared__ float4 s_col[kBlock];
     const WaveSpace& ws = p.ws;
     const mcrt_config& cfg = p.cfg;
     const uint32_t n_units = ws.counters[kCntUnits];
-    const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
+    const uint32_t spp = cfg.samples_per_pixel > 1 ? static_cast<uint32_t>(cfg.samples_per_pixel) : 1u;
     const float inv_spp = 1.0f / static_cast<float>(spp);
     const int stride = ws.stack_stride;
     const float* fb = view_of(scene_blob).hdr->background;
     const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
+    const uint32_t chunk_px = spp <= static_cast<uint32_t>(kBlock) ? static_cast<uint32_t>(kBlock) / spp : 0u;  // pixels per pass (0: a pixel per thread, serially)
+    auto put_pixel = [&](const TileGeom& tg, uint32_t i, float4 acc) __attribute__((always_inline)) {
+        const uint32_t uly = i / static_cast<uint32_t>(tg.w);
+        const int ly = static_cast<int>(uly);
+        const int lx = static_cast<int>(i - uly * static_cast<uint32_t>(tg.w));
+        const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
+        store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
+                    make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp));
+    };
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint4 d = ws.units[u];
         const TileGeom tg = tile_of(p, static_cast<int>(d.x));
         const uint32_t pp0 = d.y, pp1 = d.z;
-        for (uint32_t i = pp0 + threadIdx.x; i < pp1; i += kBlock) {
-            const uint32_t slot0 = d.w + (i - pp0) * static_cast<uint32_t>(spp);
-            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            for (int s = 0; s < spp; ++s) {
-                const uint32_t slot = slot0 + static_cast<uint32_t>(s);
-                const uint32_t code = ws.end[slot];
-                float4 c;
-                if (code == 0u) {
-                    c = ws.scol[slot];
-                } else {
-                    const float4* lv = ws.stack + static_cast<size_t>(slot) * stride;
-                    const int records = static_cast<int>(code >> 1);
-                    C4 tail = flat_bg;
-                    int dd = records - 1;
-                    if (code & 1u) {
-                        const float4 last = lv[dd];
-                        tail = clamp4(C4{last.x, last.y, last.z, last.w});
-                        --dd;
-                    }
-                    for (; dd >= 0; --dd) {
-                        const float4 sd = lv[dd];
-                        tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
-                    }
-                    c = make_float4(tail.r, tail.g, tail.b, tail.a);
+        if (chunk_px == 0u) {
+            for (uint32_t i = pp0 + threadIdx.x; i < pp1; i += kBlock) {
+                float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (uint32_t s = 0; s < spp; ++s) {
+                    const float4 c = sample_colour(ws, d.w + (i - pp0) * spp + s, stride, flat_bg);
+                    acc.x += c.x, acc.y += c.y, acc.z += c.z, acc.w += c.w;
                 }
-                acc.x += c.x;
-                acc.y += c.y;
-                acc.z += c.z;
-                acc.w += c.w;
+                put_pixel(tg, i, acc);
             }
-            const uint32_t uly = i / static_cast<uint32_t>(tg.w);
-            const int ly = static_cast<int>(uly);
-            const int lx = static_cast<int>(i - uly * static_cast<uint32_t>(tg.w));
-            const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
-            store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
-                        make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp));
+            continue;
+        }
+        for (uint32_t p0 = pp0; p0 < pp1; p0 += chunk_px) {  // uniform
+            const uint32_t npx = min(chunk_px, pp1 - p0);
+            if (threadIdx.x < npx * spp) s_col[threadIdx.x] = sample_colour(ws, d.w + (p0 - pp0) * spp + threadIdx.x, stride, flat_bg);
+            __syncthreads();
+            if (threadIdx.x < npx) {
+                float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (uint32_t s = 0; s < spp; ++s) {
+                    const float4 c = s_col[threadIdx.x * spp + s];
+                    acc.x += c.x, acc.y += c.y, acc.z += c.z, acc.w += c.w;
+                }
+                put_pixel(tg, p0 + threadIdx.x, acc);
+            }
+            __syncthreads();
         }
     }
 }
@@ -1271,21 +1375,24 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
         }
         return mx;
     };
-    // every tile of a batch (touched or not) also holds its jitter / lens draws
+    // the tiles' jitter / lens draws: of the touched tiles only when `plan_tiles` renders the background tiles
+    // itself (a pixel's draws fit one 624-word twist), of every tile of the batch otherwise
     const size_t draws_stride = tile_slots * static_cast<size_t>(p.draws_per_sample);
-    const size_t draws_row_bytes = draws_stride * 4 * static_cast<size_t>(p.shard.tiles_x);
+    p.bg_in_plan = spp * static_cast<size_t>(p.draws_per_sample) <= 624 ? 1 : 0;
+    const size_t draws_row_bytes = p.bg_in_plan ? 0 : draws_stride * 4 * static_cast<size_t>(p.shard.tiles_x);
+    const size_t draws_tile_bytes = p.bg_in_plan ? draws_stride * 4 : 0;
     p.ws.draws_stride = static_cast<uint32_t>(draws_stride > 0xffffffffull ? 0xffffffffull : draws_stride);
     p.ws.tile_slots = static_cast<uint32_t>(tile_slots > 0xffffffffull ? 0xffffffffull : tile_slots);
     // records are indexed with 32 bits (with room for the 3·S multiplier done in size_t)
     const size_t index_limit = 0x7ffffff0ull / recs;
-    size_t tile_budget = budget_bytes / (per_entry * (tile_slots ? tile_slots : 1));
+    size_t tile_budget = budget_bytes / (per_entry * (tile_slots ? tile_slots : 1) + draws_tile_bytes);
     if (tile_slots && tile_budget > index_limit / tile_slots) tile_budget = index_limit / tile_slots;
     int rows = owned > 0 ? owned : 1;
     // a batch of R rows fits when its hit workspace and its draws fit the budget together
     auto fits = [&](int R) -> bool {
         const size_t f = fullest(R);
         if (f > tile_budget) return false;
-        return f * tile_slots * per_entry + static_cast<size_t>(R) * draws_row_bytes <= budget_bytes;
+        return f * (tile_slots * per_entry + draws_tile_bytes) + static_cast<size_t>(R) * draws_row_bytes <= budget_bytes;
     };
     if (owned > 0 && !fits(rows)) {  // largest R that fits (monotone in R)
         int lo = 1, hi = owned;
@@ -1305,7 +1412,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     p.ws.cap = static_cast<uint32_t>(cap);
     p.ws.tile_cap = static_cast<uint32_t>(cap_tiles);
     w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 : 0;
-    w.tile_draws = static_cast<size_t>(rows) * draws_row_bytes;
+    w.tile_draws = static_cast<size_t>(rows) * draws_row_bytes + cap_tiles * draws_tile_bytes;
     w.scol = cap * 16;
     w.end = cap * 4;
     p.ws.unit_cap = static_cast<uint32_t>(cap_tiles * static_cast<size_t>(p.parts_per_tile));
@@ -1381,7 +1488,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
         hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 1) * 4, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
-                           p.scene, p.tile_rng, p.ws.tile_draws, p, tile_base, batch_tiles);
+                           p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
         const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
         if (p.scene_in_lds && !p.scene_posed) {
             hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
