@@ -6,19 +6,29 @@
 A *step* is one render of the BASELINE.json north-star frame (configs[1]: 1920x1080, 4 bounces,
 4 samples/pixel, one light, synthetic 64x64 skin with inner+outer layer, `RayTracer::Config`
 defaults otherwise) with the flattened scene already resident in HBM; the output is the float4
-framebuffer in HBM.  F frames (default 4) are in flight: step k uses scene handle / stream / output
-buffer k mod F, every frame is rendered completely (`--check` compares each buffer with a lone
-render); `latency_ms` and `kernel.pipeline_ms` report the one-frame-at-a-time figures next to the
-throughput.  N > 1 (launched by torch.distributed.run, one process per GPU): the SAME frame is
-sharded by cyclic tile rows (rank r renders tile rows r, r+N, ...), each rank renders into a packed
-buffer and an RCCL gather over xGMI assembles the frame on rank 0 (strong scaling: the total work
-is fixed); gathers overlap the renders of the following steps.
+framebuffer in HBM.  Three figures describe it, all in the line:
 
-Rank 0 prints ONE JSON line: metric/value per BASELINE.json plus `roofline` (algorithmic bytes, 16 B
-per output pixel, over the hipEvent-measured duration of one frame's pipeline — this path is
-VALU-bound; VALU-pipe busy and HBM traffic from the PMC passes are in profiles/) and,
-at N = 1, `cpu_baseline` (the compiled reference, or the oracle port when oracle/_ref is absent,
-timed on this box's host cores on a bounded sample).
+  value / ms_per_step   DEVICE THROUGHPUT with F frames (default 4) in flight: step k uses scene handle / stream /
+                        output buffer k mod F, every frame is rendered completely (`--check` compares each buffer
+                        with a lone render).  This is the contract's `value` (inputs resident in HBM).
+  latency_ms            one frame at a time on the device: enqueue, wait, repeat (library defaults: the render
+                        spreads itself over 2 internal streams); kernel.pipeline_ms is the same frame on ONE
+                        stream, measured with hipEvents on that stream.
+  render_call           SURVEY.md §8(d)'s metric: wall time of ONE `TileRenderer::render()` call through the C ABI
+                        (mcrt_render: scene flatten + upload + kernels + download into host memory + progress
+                        callbacks), median of >= 10 calls after 2 warm-ups, with the library's own split.
+
+N > 1 (launched by torch.distributed.run, one process per GPU): the SAME frame is sharded by cyclic tile
+rows (rank r renders tile rows r, r+N, ...), each rank renders into a packed buffer and an RCCL gather over
+xGMI assembles the frame on rank 0 (strong scaling: the total work is fixed); gathers overlap the renders of
+the following steps.
+
+Rank 0 prints ONE JSON line: metric/value per BASELINE.json plus `roofline` — algorithmic bytes (16 B per
+output pixel) over the hipEvent-measured duration of one frame's pipeline against the HBM peak, the HBM
+traffic and the VALU wave-instructions per frame from the committed PMC passes (profiles/pmc_traffic.json),
+and from those the VALU fraction against 78.6 T lane-ops/s: this path is VALU-bound, see DESIGN.md — and, at
+N = 1, `cpu_baseline` (the compiled reference, or the oracle port when oracle/_ref is absent, timed on this
+box's host cores on a bounded sample).
 """
 from __future__ import annotations
 
@@ -28,6 +38,8 @@ import os
 import statistics
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,13 +53,21 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TLOPS = 78.6  # 157.3 TFLOP/s fp32 vector = 78.6 T non-FMA lane-ops/s
 
 WORKLOADS = {
-    # name: (width, height, bounces, spp, skin, pose)
+    # name: (width, height, bounces, spp, skin, pose[, extra Config fields])
     "1080p_b4_spp4_S64": (1920, 1080, 4, 4, "S64", 0),  # BASELINE.json configs[1] — the metric's config
     "4k_b8_spp16_S64": (3840, 2160, 8, 16, "S64", 0),  # configs[2]
     "4k_b4_spp4_S64": (3840, 2160, 4, 4, "S64", 0),  # configs[3]
     "8k_b8_spp64_S32": (7680, 4320, 8, 64, "S32", 0),  # configs[4] (single reference light)
     "256_b1_spp1_S64": (256, 256, 1, 1, "S64", 0),  # configs[0]
+    # what the reference GUI renders by default (main_window.cpp:242-348 as the reference states it):
+    # 1920x1080, 4 bounces, 64 spp, AO 16 samples, depth of field aperture 0.3, soft shadows 8
+    "gui_defaults": (1920, 1080, 4, 64, "S64", 0, dict(aoEnabled=True, aoSamples=16, dofEnabled=True, aperture=0.3)),
 }
+
+
+def workload_config(M, name: str):
+    w, h, b, spp, skin, pose, *extra = WORKLOADS[name]
+    return M.Config(width=w, height=h, maxBounces=b, samplesPerPixel=spp, **(extra[0] if extra else {})), skin, pose
 
 
 def cpu_baseline(workload: str, frames: int = 3) -> dict:
@@ -57,11 +77,11 @@ def cpu_baseline(workload: str, frames: int = 3) -> dict:
     import oraclelib
     import minecraftskin_raytracer_amd as M
 
-    w, h, b, spp, skin, pose = WORKLOADS[workload]
+    cfg, skin, pose = workload_config(M, workload)
+    w, h = cfg.width, cfg.height
     kind = "reference" if oraclelib.Reference.available() else "port"
     lib = oraclelib.Reference() if kind == "reference" else oraclelib.Oracle()
     sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
-    cfg = M.Config(width=w, height=h, maxBounces=b, samplesPerPixel=spp)
     times = []
     budget_s = 30.0
     t_all = time.perf_counter()
@@ -124,8 +144,8 @@ def main() -> None:
         else:
             dist.init_process_group("gloo")
 
-    w, h, bounces, spp, skin, pose = WORKLOADS[args.workload]
-    cfg = M.Config(width=w, height=h, maxBounces=bounces, samplesPerPixel=spp)
+    cfg, skin, pose = workload_config(M, args.workload)
+    w, h, bounces, spp = cfg.width, cfg.height, cfg.maxBounces, cfg.samplesPerPixel
     sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
     # F frames in flight: frame k is rendered by scene handle / stream / buffers k mod F.  One frame's
     # pipeline is a chain of ~16 dependent kernels with ~0.2 ms of fixed latency; a renderer that
@@ -219,28 +239,55 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # one frame at a time (rank-local render only): enqueue, wait, repeat (same single-lane setting as
-    # the timed loop; the library's automatic 2-lane split of a lone 1080p frame gives 0.49 ms with the
-    # runtime's default 4 hardware queues, profiles/r01_v4)
+    # one frame at a time (rank-local render only): enqueue, wait, repeat — on a handle of its own with the
+    # library's defaults (a lone frame spreads itself over internal streams, mcrt_scene_set_lanes(0))
     lat_n = max(5, min(args.steps, 30))
     lat_target = frames[0] if world == 1 else packed[0]
+    first, stepn = (0, 1) if world == 1 else (rank, world)
+    layout = abi.LAYOUT_FRAME if world == 1 else abi.LAYOUT_PACKED
+    stream = streams[0].cuda_stream
+    lone = M.DeviceScene(sd, device=local_rank)
+    for _ in range(6):  # workspace allocation, launch recording (4th render of a parameter set)
+        lone.render_device(cfg, lat_target.data_ptr(), first, stepn, layout, stream)
     torch.cuda.synchronize()
     t_lat = time.perf_counter()
     for _ in range(lat_n):
-        if world == 1:
-            scene.render_device(cfg, lat_target.data_ptr(), 0, 1, abi.LAYOUT_FRAME, streams[0].cuda_stream)
-        else:
-            scene.render_device(cfg, lat_target.data_ptr(), rank, world, abi.LAYOUT_PACKED, streams[0].cuda_stream)
+        lone.render_device(cfg, lat_target.data_ptr(), first, stepn, layout, stream)
         torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t_lat) / lat_n * 1e3
-    stream = streams[0].cuda_stream
+    lone.check()
+    lone.close()
 
-    # kernel-only duration of the dominant (trace) kernel: hipEvents on the launch stream
-    first, stepn = (0, 1) if world == 1 else (rank, world)
-    layout = abi.LAYOUT_FRAME if world == 1 else abi.LAYOUT_PACKED
+    # device-only duration of one frame's pipeline on ONE stream: hipEvents on the launch stream
     target = frame if world == 1 else packed[0]
-    render_ms, trace_ms = scene.time_render_device(cfg, target.data_ptr(), max(5, min(args.steps, 50)), first, stepn, layout, stream)
+    pipeline_ms = scene.time_render_device(cfg, target.data_ptr(), max(5, min(args.steps, 50)), first, stepn, layout, stream)
     torch.cuda.synchronize()
+
+    # wall time of one TileRenderer::render() call through the C ABI, host buffer in, host buffer out
+    render_call = None
+    if world == 1 and rank == 0:
+        host = np.zeros((h, w, 4), np.float32)
+        walls, splits = [], []
+        for i in range(2 + max(10, min(args.steps, 20))):
+            t0 = time.perf_counter()
+            M.TileRenderer.render(sd, cfg, out=host)
+            dt = (time.perf_counter() - t0) * 1e3
+            if M.TileRenderer.lastErrors():
+                raise SystemExit(f"render failed: {M.TileRenderer.lastErrors()}")
+            if i >= 2:
+                walls.append(dt)
+                splits.append(M.TileRenderer.lastTimings())
+        med = statistics.median(walls)
+        render_call = {
+            "ms": round(med, 4),
+            "mpixels_per_s": round(w * h / med / 1e3, 2),
+            "calls": len(walls),
+            "min_ms": round(min(walls), 4),
+            "split_ms": {k: round(statistics.median(t[k] for t in splits), 4) for k in splits[0]},
+            "what": "median wall time of mcrt_render (the TileRenderer::render drop-in) into a caller-owned host frame: scene flatten + "
+                    "upload + kernels + row-group downloads overlapping the render + progress bookkeeping; the Python wrapper's own "
+                    "Image allocation is outside (a reused buffer)",
+        }
 
     check = None
     if args.check and rank == 0:
@@ -255,14 +302,40 @@ def main() -> None:
         owned_rows = scene.owned_pixel_rows(cfg, first, stepn)
         owned_px = min(owned_rows, h) * w if world > 1 else w * h
         algo_bytes = 16.0 * owned_px  # 16 B written per output pixel, ~0 read
-        achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
-        traffic = None
+        achieved = algo_bytes / (pipeline_ms * 1e-3) / 1e9
+        # counters of one frame of this workload from the committed rocprofv3 --pmc passes (tools/pmc_run.sh)
+        pmc = {}
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(args.workload)
+                pmc = json.load(open(prof)).get(args.workload) or {}
+                if not isinstance(pmc, dict):  # older files held the traffic alone
+                    pmc = {"hbm_bytes": pmc}
             except Exception:
-                traffic = None
+                pmc = {}
+        traffic = pmc.get("hbm_bytes")
+        valu = pmc.get("valu_wave_instructions")
+        roof = {
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic,
+            "kernel": "one frame's whole pipeline on one stream (kernel.pipeline_ms; the per-kernel split is in " + str(pmc.get("profile", "profiles/")) + ")",
+            "algorithmic_bytes": algo_bytes,
+            "note": "algorithmic bytes = 16 B x output pixels of the frame; the path is VALU/latency-bound by construction (DESIGN.md), "
+                    "so the HBM fraction is << 1 %: the VALU figures are the ones that describe kernel quality",
+        }
+        if traffic and world == 1:
+            roof["traffic_over_algorithmic"] = round(traffic / algo_bytes, 2)
+            roof["hbm_traffic_gbs_pipelined"] = round(traffic / (ms_per_step * 1e-3) / 1e9, 1)
+        if valu and world == 1:
+            lane_ops = valu * 64.0  # a wave-instruction = 64 lane-ops
+            roof["valu_wave_instructions"] = valu
+            roof["valu_peak_tlaneops"] = VALU_PEAK_TLOPS
+            roof["valu_frac"] = round(lane_ops / (pipeline_ms * 1e-3) / (VALU_PEAK_TLOPS * 1e12), 4)  # one frame at a time
+            roof["valu_frac_pipelined"] = round(lane_ops / (ms_per_step * 1e-3) / (VALU_PEAK_TLOPS * 1e12), 4)  # at `value`
         line = {
             "metric": "Mpixels/s",
             "value": round(mpix, 2),
@@ -277,28 +350,24 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{w}x{h}, {bounces} bounces, {spp} spp, 1 light, synthetic 64x{64 if skin == 'S64' else 32} skin ({skin}), pose {pose}, soft shadows 8, tile 32",
+                "workload": f"{w}x{h}, {bounces} bounces, {spp} spp, 1 light, synthetic 64x{64 if skin == 'S64' else 32} skin ({skin}), pose {pose}, soft shadows 8, tile 32"
+                            + (", AO 16, DOF aperture 0.3 (reference GUI defaults)" if args.workload == "gui_defaults" else ""),
                 "name": args.workload,
+                "value_is": f"device throughput, {F} frame(s) in flight, scene and frame resident in HBM; latency_ms = one frame at a time; "
+                            "render_call.ms = one host-to-host TileRenderer::render call (SURVEY 8d)",
                 "parallelism": "single GPU" if world == 1 else f"cyclic tile rows over {world} GPUs + RCCL gather to rank 0 (overlapped)",
                 "frames_in_flight": F,
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             },
             "latency_ms": round(latency_ms, 4),
-            "kernel": {"pipeline_ms": round(trace_ms, 4),
-                       "note": "hipEvents on the launch stream around one frame's whole pipeline (seed, plan_tiles, primary, light_samples, "
-                               "[shadow, shade] x levels, resolve); per-kernel split: profiles/"},
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                "kernel": "whole wavefront pipeline of one frame (level-0 stages: shade 90 us, shadow 78, light_samples 70, primary 55, plan_tiles 33; profiles/r01_v8)",
-                "note": "algorithmic bytes = 16 B x output pixels per frame; the path is VALU/latency-bound by construction "
-                        "(DESIGN.md): VALU issue (4-cycle cadence) 39 % of one frame's chain, 71 % with four frames in flight (profiles/r01_v8)",
-            },
+            "latency_mpixels_per_s": round(w * h / latency_ms / 1e3, 2),
+            "kernel": {"pipeline_ms": round(pipeline_ms, 4),
+                       "note": "hipEvents on the launch stream around one frame's whole pipeline on one stream (plan_tiles, primary, bounce, chase, "
+                               "light_samples, shadow, shade, resolve)"},
+            "roofline": roof,
         }
+        if render_call is not None:
+            line["render_call"] = render_call
         if check is not None:
             line["check_assembled_frame_equals_single_gpu_render"] = check
         if world == 1 and not args.no_cpu_baseline:

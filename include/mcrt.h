@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCRT_ABI_VERSION 1
+#define MCRT_ABI_VERSION 2 /* 2: mcrt_render_multi, MCRT_DEVICE_ALL; mcrt_time_render_device lost its second output */
 
 /* error codes (0 = ok) */
 #define MCRT_OK 0
@@ -120,15 +120,34 @@ int mcrt_device_count(void);
 const char* mcrt_last_error(void);
 
 /* ---- render: host buffers (the TileRenderer::render drop-in) ------------------------------
- * Renders the whole frame on `device` (>= 0) and copies it into out_rgba (width*height*4
- * floats, row-major, caller-owned).  `progress`, if non-NULL, is invoked exactly totalTiles times
- * with done = 1..total on the calling thread (tile_renderer.cpp:168-172 contract).
+ * Renders the whole frame on `device` (>= 0; MCRT_DEVICE_ALL = every visible device, see
+ * mcrt_render_multi) and copies it into out_rgba (width*height*4 floats, row-major, caller-owned).
+ * Tile rows travel to the host as soon as they are final, while the rest of the frame still renders:
+ * rows that hold only background right behind the first kernel, the rows of a pass behind that pass
+ * when a large frame takes several.  `progress`, if non-NULL, is invoked exactly totalTiles times
+ * with done = 1..total on the calling thread (tile_renderer.cpp:168-172 contract), for each row group
+ * as it has landed in out_rgba.
  * Invalid sizes (any of width/height/tile_size <= 0) → MCRT_OK with nothing written, like the
- * reference returning an untouched Image (tile_renderer.cpp:144-146).
+ * reference returning an untouched Image (tile_renderer.cpp:144-146).  max_bounces above 4000 →
+ * MCRT_ERR_INVALID (the workspace holds one colour per level and sample).
  * There is no CPU fallback: without a usable HIP device this returns MCRT_ERR_NO_DEVICE. */
 typedef void (*mcrt_progress_fn)(int done, int total, void* user);
+#define MCRT_DEVICE_ALL (-1)
 int mcrt_render(const mcrt_scene_desc* scene, const mcrt_config* cfg, float* out_rgba,
                 mcrt_progress_fn progress, void* user, int device);
+
+/* The same frame spread over several devices of the node, one process: rank r of
+ * n_devices renders tile rows r, r+n, r+2n, ... (cyclic — the figure occupies the middle rows) on
+ * devices[r] with a replica of the scene; no collective inside the render.  devices = NULL or
+ * n_devices <= 0: every visible device.  A device may be listed more than once (each entry is a rank
+ * with its own workspace), which is how the path is tested on a one-GPU box.
+ *   gather = 0  every device downloads its own rows straight into out_rgba: n PCIe links in parallel,
+ *               no device-to-device traffic; the frame is assembled by the copies themselves
+ *   gather = 1  the ranks' packed rows travel to devices[0] by peer copies (xGMI), one launch
+ *               un-permutes them there (mcrt_assemble_frame_device), one download brings the frame back
+ * Results are bit-identical to mcrt_render on one device.  Progress and errors as for mcrt_render. */
+int mcrt_render_multi(const mcrt_scene_desc* scene, const mcrt_config* cfg, float* out_rgba,
+                      mcrt_progress_fn progress, void* user, const int* devices, int n_devices, int gather);
 
 /* TileRenderer::renderTile (tile_renderer.cpp:71-127): renders the one tile with row-major index
  * tile_index (generateTiles order) and writes its pixels into frame_rgba, a full width*height
@@ -167,8 +186,13 @@ int mcrt_scene_check(mcrt_scene* scene);
 
 /* A render is spread over internal *lanes* (streams with their own workspace, every n-th tile row of
  * the shard each, forked from / joined to the caller's stream) when the shard is large enough.
- * lanes = 0 restores that automatic choice, lanes >= 1 forces a count (at most 4).  A caller that
- * already keeps several frames in flight on its own streams should use 1. */
+ * lanes = 0 restores that automatic choice, lanes >= 1 forces a count (at most 4).
+ * One scene handle = one frame in flight: every render of a handle uses the handle's workspace, so
+ * renders of one handle run one after the other on the device whatever streams they are given (the
+ * library chains them with an event).  A caller that wants several frames in flight creates one
+ * handle per frame in flight — and should then use lanes = 1, its frames already fill the chip.
+ * Streams of the HIP runtime share its hardware queues (4 by default): more than 4 streams that
+ * should run concurrently need GPU_MAX_HW_QUEUES set before the runtime initialises (bench.py: 8). */
 int mcrt_scene_set_lanes(mcrt_scene* scene, int lanes);
 
 /* Same render with the quantisation fused into the epilogue: writes the float4 frame to d_out_f32
@@ -212,20 +236,21 @@ int mcrt_write_png_f32(const char* path, const float* rgba, int width, int heigh
  * return MCRT_ERR_INVALID (writePNG rejects empty images, image_writer.cpp:7-9). */
 int mcrt_render_png(const mcrt_scene_desc* scene, const mcrt_config* cfg, const char* path, int device);
 
-/* timings of the last mcrt_render() on this thread, milliseconds */
+/* timings of the last mcrt_render() / mcrt_render_multi() on this thread, milliseconds: flatten_ms — scene
+ * flattening on the host; h2d_ms — uploads, workspace checks and every launch call; kernel_ms — rank 0's
+ * pipeline on its device (hipEvents); d2h_ms — from the last launch call until the last row has landed
+ * (it overlaps the render); total_ms — the whole call */
 typedef struct mcrt_timings {
     float flatten_ms, h2d_ms, kernel_ms, d2h_ms, total_ms;
 } mcrt_timings;
 int mcrt_last_timings(mcrt_timings* out);
 
-/* Kernel-only timing helper used by bench.py: enqueues `iters` renders of the given shard on
+/* Device-only timing helper used by bench.py: enqueues `iters` renders of the given shard on
  * `stream`, each bracketed by hipEvents recorded on that same stream and waited for, and returns
- * the average duration in ms of one render's whole pipeline (seeding pre-pass, every lane and
- * level, resolve).  Both outputs carry that figure (the second one used to time the single trace
- * kernel of an earlier design and is kept for ABI stability). */
+ * the average duration in ms of one render's whole pipeline (every lane and kernel of the frame). */
 int mcrt_time_render_device(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_first,
                             int tile_row_step, int out_layout, float* d_out_rgba, void* stream,
-                            int iters, float* avg_render_ms, float* avg_trace_kernel_ms);
+                            int iters, float* avg_render_ms);
 
 /* ---- scene construction helpers (MeshBuilder / SkinParser layout) -------
  * Build the reference's character scene from an RGBA8 skin image (64x64 or 64x32), exactly as

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "mcrt_scene_desc_free", "mcrt_scene_flatten", "mcrt_probe_intersect", "mcrt_probe_trace",
     "mcrt_probe_mt_uniform", "mcrt_probe_detmath", "mcrt_probe_detmath_range",
     "mcrt_render_device_ex", "mcrt_write_png_rgba8", "mcrt_encode_png_rgba8", "mcrt_write_png_f32", "mcrt_render_png",
-    "mcrt_assemble_frame_device", "mcrt_scene_set_lanes", "mcrt_trim", "mcrt_scene_check",
+    "mcrt_assemble_frame_device", "mcrt_scene_set_lanes", "mcrt_trim", "mcrt_scene_check", "mcrt_render_multi",
 ]
 
 
@@ -66,7 +66,8 @@ def load():
         "mcrt_quantize_rgba8_device": (C.c_int, [vp, vp, C.c_size_t, vp]),
         "mcrt_quantize_rgba8": (None, [f_p, u8_p, C.c_size_t]),
         "mcrt_last_timings": (C.c_int, [C.POINTER(abi.McrtTimings)]),
-        "mcrt_time_render_device": (C.c_int, [vp, cfg_p, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, f_p, f_p]),
+        "mcrt_time_render_device": (C.c_int, [vp, cfg_p, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, f_p]),
+        "mcrt_render_multi": (C.c_int, [desc_p, cfg_p, f_p, abi.PROGRESS_FN, vp, C.POINTER(C.c_int), C.c_int, C.c_int]),
         "mcrt_build_skin_scene": (C.c_int, [u8_p, C.c_int, C.c_int, f_p, C.POINTER(desc_p)]),
         "mcrt_build_default_scene": (C.c_int, [f_p, C.POINTER(desc_p)]),
         "mcrt_builtin_pose": (C.c_int, [C.c_int, f_p]),

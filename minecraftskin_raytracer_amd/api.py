@@ -28,9 +28,17 @@ def device_count() -> int:
     return int(load().mcrt_device_count())
 
 
+class _OwnedDescPtr(C.POINTER(abi.McrtSceneDesc)):
+    """A ``POINTER(McrtSceneDesc)`` that keeps the object owning the pointed-to arrays alive: a ``.ptr`` taken
+    from a temporary (``skin_scene(...).ptr``) stays valid for as long as the pointer itself is referenced."""
+
+    _type_ = abi.McrtSceneDesc
+
+
 class SceneDesc:
     """A scene description the library can consume: either built from a Python ``Scene`` or owned by
-    the native scene builder.  ``.ptr`` is a ``POINTER(McrtSceneDesc)``-compatible object."""
+    the native scene builder.  ``.ptr`` is a ``POINTER(McrtSceneDesc)``-compatible object that holds a
+    reference to this description."""
 
     def __init__(self, scene: Optional[Scene] = None, _native=None):
         self._holder = SceneDescHolder(scene) if scene is not None else None
@@ -38,7 +46,10 @@ class SceneDesc:
 
     @property
     def ptr(self):
-        return self._native if self._native is not None else self._holder.ptr
+        raw = self._native if self._native is not None else C.pointer(self._holder.desc)
+        p = C.cast(raw, _OwnedDescPtr)
+        p._owner = self  # the description (and through it the arrays) lives as long as the pointer
+        return p
 
     @property
     def desc(self) -> abi.McrtSceneDesc:
@@ -115,21 +126,38 @@ class TileRenderer:
 
     @staticmethod
     def render(scene, config: Config, progressCallback: Optional[Callable[[int, int], None]] = None,
-               device: int = 0) -> Image:
+               device=0, gather: bool = False, out: Optional[np.ndarray] = None) -> Image:
         """TileRenderer::render.  Per-frame failures never raise (tile_renderer.cpp:158-166): they are
         recorded as one ``(-1, message)`` entry in ``lastErrors()`` and the image keeps Color() =
-        (0,0,0,1) pixels."""
+        (0,0,0,1) pixels.
+
+        ``device``: an index, ``"all"`` / ``-1`` (every visible device) or a sequence of indices — one rank per
+        entry, cyclic tile rows (mcrt_render_multi; ``gather`` selects the peer-copy assembly on the first
+        device instead of per-device downloads).  ``out``: a (H, W, 4) float32 C-contiguous array to render
+        into (the reference returns a fresh Image per call; a caller that renders repeatedly can keep one)."""
         lib = load()
         d = _as_desc(scene)
         c = config.to_c()
         w, h = max(config.width, 0), max(config.height, 0)
-        out = np.zeros((h, w, 4), np.float32)
-        out[..., 3] = 1.0  # Image(w,h): default Color() = (0,0,0,1)
+        if out is None:
+            out = np.zeros((h, w, 4), np.float32)
+            out[..., 3] = 1.0  # Image(w,h): default Color() = (0,0,0,1)
+        elif out.shape != (h, w, 4) or out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous (height, width, 4) float32 array")
         TileRenderer._errors = []
         if w == 0 or h == 0 or config.tileSize <= 0:
             return out
         cb = abi.PROGRESS_FN((lambda done, total, _u: progressCallback(done, total))) if progressCallback else C.cast(None, abi.PROGRESS_FN)
-        rc = lib.mcrt_render(d.ptr, C.byref(c), abi.fptr(out), cb, None, device)
+        if isinstance(device, str):
+            if device != "all":
+                raise ValueError("device must be an index, 'all' or a sequence of indices")
+            device = -1
+        if isinstance(device, int) and device >= 0:
+            rc = lib.mcrt_render(d.ptr, C.byref(c), abi.fptr(out), cb, None, device)
+        else:
+            devs = [] if isinstance(device, int) else [int(x) for x in device]
+            arr = (C.c_int * max(len(devs), 1))(*devs)
+            rc = lib.mcrt_render_multi(d.ptr, C.byref(c), abi.fptr(out), cb, None, arr if devs else None, len(devs), 1 if gather else 0)
         if rc != 0:
             TileRenderer._errors = [(-1, lib.mcrt_last_error().decode("utf-8", "replace"))]
             out[...] = 0.0
@@ -239,13 +267,13 @@ class DeviceScene:
                                            C.c_void_p(out_rgba8_ptr or None), C.c_void_p(stream)))
 
     def time_render_device(self, config: Config, out_ptr: int, iters: int, first: int = 0, step: int = 1,
-                           layout: int = abi.LAYOUT_FRAME, stream: int = 0) -> Tuple[float, float]:
-        """Returns (avg ms per render, avg ms of the trace kernel), measured with hipEvents on `stream`."""
+                           layout: int = abi.LAYOUT_FRAME, stream: int = 0) -> float:
+        """Average ms of one render's whole pipeline on the device, measured with hipEvents on `stream`."""
         c = config.to_c()
-        a, b = C.c_float(), C.c_float()
+        a = C.c_float()
         check(load().mcrt_time_render_device(self._h, C.byref(c), first, step, layout, C.c_void_p(out_ptr),
-                                             C.c_void_p(stream), iters, C.byref(a), C.byref(b)))
-        return float(a.value), float(b.value)
+                                             C.c_void_p(stream), iters, C.byref(a)))
+        return float(a.value)
 
     # ---- probes (per-function parity tests) ----
     def intersect(self, rays: np.ndarray) -> np.ndarray:

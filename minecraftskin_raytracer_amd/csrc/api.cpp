@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <utility>
 #include <string>
 #include <thread>
 #include <vector>
@@ -138,6 +140,16 @@ struct mcrt_scene {
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     bool flags_checked = true;  // no render since mcrt_scene_check last read (and cleared) the lanes' overflow words
+    // the one-shot host path (mcrt_render & co): frame buffer, streams and events kept with the pooled workspace
+    DeviceBuffer frame;                // float4 frame / packed rows / RGBA8 plane of a host-buffer render
+    hipStream_t main_stream = nullptr;  // the render
+    hipStream_t copy_stream = nullptr;  // downloads of finished tile rows, overlapping the render
+    std::vector<hipEvent_t> marks;      // event pool of the row-group downloads
+    size_t marks_used = 0;
+    // pinned host staging for the small transfers of every call (the scene blob up, the lanes' flag words
+    // back): no pin / unpin of a few KB of pageable memory per call
+    void* staging = nullptr;
+    size_t staging_bytes = 0;
 };
 
 namespace {
@@ -147,13 +159,10 @@ namespace {
 // workspace is sized for the worst case of every sample hitting (~300 B per sample), buffers only
 // ever grow to what a frame needs, and a frame cut into few large batches is much faster than many
 // small ones (4K / 8 bounces / 16 spp: 9.7 ms with 4 GiB, 6.1 ms in one batch).
-size_t workspace_budget() {
-    static const size_t v = [] {
-        const char* e = std::getenv("MCRT_WORKSPACE_MB");
-        long long mb = e ? std::atoll(e) : 0;
-        return static_cast<size_t>(mb > 0 ? mb : 96 * 1024) << 20;
-    }();
-    return v;
+size_t workspace_budget() {  // read per scene: tests switch it between renders
+    const char* e = std::getenv("MCRT_WORKSPACE_MB");
+    const long long mb = e ? std::atoll(e) : 0;
+    return static_cast<size_t>(mb > 0 ? mb : 96 * 1024) << 20;
 }
 
 // lanes for a shard: enough work per lane that the extra launches pay (MCRT_LANES forces a count)
@@ -233,7 +242,7 @@ void touched_tiles_per_row(const mcrt_scene* sc, const mcrt_config& cfg, const S
 // fill RenderParams for lane `li` of `n_lanes` over the shard (first, step) + make sure its
 // workspace exists (allocation only when it has to grow)
 int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int first, int step, int layout, float* d_out,
-            uint8_t* d_out8, RenderParams& p) {
+            uint8_t* d_out8, RenderParams& p, std::vector<int>* row_touched_out = nullptr) {
     Lane* s = &sc->lanes[li];
     std::memset(&p, 0, sizeof p);
     p.scene = static_cast<const uint8_t*>(sc->blob.ptr);
@@ -297,6 +306,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         s->counters.release(), s->hit_rng.release();
         sc->budget /= 2;
     }
+    if (row_touched_out) *row_touched_out = row_touched;
     p.tile_rng = w.tile_rng ? static_cast<uint32_t*>(s->tile_rng.ptr) : nullptr;
     WaveSpace& ws = p.ws;
     ws.tile_draws = static_cast<float*>(s->tile_draws.ptr);
@@ -323,18 +333,19 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
 }
 
 // the launches of one render on `stream`: lanes fork from and join the stream
-int launch_lanes(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream) {
+// marks: per lane, or nullptr
+int launch_lanes(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream, const LaunchMarks* marks = nullptr) {
     if (n_lanes > 1) {
         if (!s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(s->fork, stream));
         for (int li = 1; li < n_lanes; ++li) {
             Lane& ln = s->lanes[li];
             HIP_TRY(hipStreamWaitEvent(ln.stream, s->fork, 0));
-            HIP_TRY(launch_render(p[li], ln.stream));
+            HIP_TRY(launch_render(p[li], ln.stream, marks ? &marks[li] : nullptr));
             HIP_TRY(hipEventRecord(ln.done, ln.stream));
         }
     }
-    HIP_TRY(launch_render(p[0], stream));
+    HIP_TRY(launch_render(p[0], stream, marks ? &marks[0] : nullptr));
     for (int li = 1; li < n_lanes; ++li) HIP_TRY(hipStreamWaitEvent(stream, s->lanes[li].done, 0));
     return MCRT_OK;
 }
@@ -428,17 +439,34 @@ int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStrea
     return MCRT_OK;
 }
 
-// enqueue one render of the shard (first, step) on `stream`
+// Tile rows that become final together, for a caller that downloads rows while the rest still renders.
+struct RowGroup {
+    std::vector<hipEvent_t> wait;  // recorded events after which the rows are complete in device memory
+    std::vector<int> rows;         // tile-row indices in the frame
+};
+hipEvent_t next_mark(mcrt_scene* s) {  // pooled per scene shell
+    if (s->marks_used == s->marks.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        s->marks.push_back(e);
+    }
+    return s->marks[s->marks_used++];
+}
+
+// enqueue one render of the shard (first, step) on `stream`.  groups != nullptr (one-shot host path): the
+// launches also record events that tell when which tile rows are final, *groups lists them in
+// completion order (direct launches, no graph replay: the events are this call's own).
 int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, uint8_t* d_out8,
-                   hipStream_t stream, bool may_record = true) {
+                   hipStream_t stream, bool may_record = true, std::vector<RowGroup>* groups = nullptr) {
     const Shard whole = make_shard(*cfg, first, step);
     if (whole.owned_rows <= 0) return MCRT_OK;
     if (cfg->max_bounces > kMaxBounces) return fail(MCRT_ERR_INVALID, "max_bounces above 4000 is not supported (one stack slot per level and sample)");
     const int n_lanes = lane_count(s, *cfg, whole);
     RenderParams p[kMaxLanes];
     std::memset(p, 0, sizeof p);
+    std::vector<int> row_touched[kMaxLanes];
     for (int li = 0; li < n_lanes; ++li) {
-        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li]);
+        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li], groups ? &row_touched[li] : nullptr);
         if (rc != MCRT_OK) return rc;
         Lane& ln = s->lanes[li];
         if (li > 0 && !ln.stream) {
@@ -449,6 +477,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     if (n_lanes > 1 && !s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;  // the caller records a graph of its own
+    if (capturing && groups) return fail(MCRT_ERR_INVALID, "row-group events cannot be recorded into a caller's graph");
     // all renders of a handle share its workspace: they run one after the other whatever streams they are given
     if (!capturing && s->have_last && s->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->last_done, 0));
     s->flags_checked = false;
@@ -462,9 +491,60 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
         HIP_TRY(launch_seed_tiles(p[li], stream));
         ln.rng_key = capturing ? RngKey{} : k;  // a captured seeding pass runs when the caller's graph does, not now
     }
-    const int rc = capturing ? launch_lanes(s, p, n_lanes, stream) : launch_or_replay(s, p, n_lanes, stream, may_record);
+    if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
+    int rc;
+    if (groups) {
+        // which rows are final when: a row that holds no touched tile is complete behind plan_tiles (which
+        // renders background tiles itself); the rows of a pass behind its resolve; everything at the end
+        LaunchMarks marks[kMaxLanes];
+        std::vector<hipEvent_t> batch_events[kMaxLanes];
+        RowGroup early, late;
+        std::vector<RowGroup> per_batch;
+        for (int li = 0; li < n_lanes; ++li) {
+            const RenderParams& q = p[li];
+            const int batches = (q.shard.owned_rows + q.rows_per_batch - 1) / q.rows_per_batch;
+            auto row_of = [&](int j) { return q.shard.first + j * q.shard.step; };
+            if (batches <= 1) {
+                hipEvent_t planned = nullptr;
+                if (q.bg_in_plan) {
+                    planned = next_mark(s);
+                    if (!planned) return fail(MCRT_ERR_HIP, "event creation failed");
+                    marks[li].after_plan = planned;
+                    early.wait.push_back(planned);
+                }
+                for (int j = 0; j < q.shard.owned_rows; ++j) {
+                    const bool background_only = planned && static_cast<size_t>(j) < row_touched[li].size() && row_touched[li][static_cast<size_t>(j)] == 0;
+                    (background_only ? early : late).rows.push_back(row_of(j));
+                }
+            } else {
+                batch_events[li].resize(static_cast<size_t>(batches));
+                for (int b = 0; b < batches; ++b) {
+                    hipEvent_t e = next_mark(s);
+                    if (!e) return fail(MCRT_ERR_HIP, "event creation failed");
+                    batch_events[li][static_cast<size_t>(b)] = e;
+                    RowGroup g;
+                    g.wait.push_back(e);
+                    for (int j = b * q.rows_per_batch; j < q.shard.owned_rows && j < (b + 1) * q.rows_per_batch; ++j) g.rows.push_back(row_of(j));
+                    per_batch.push_back(std::move(g));
+                }
+                marks[li].batch_done = batch_events[li].data();
+                marks[li].n_batch_done = batches;
+            }
+        }
+        rc = launch_lanes(s, p, n_lanes, stream, marks);
+        if (rc == MCRT_OK) {
+            HIP_TRY(hipEventRecord(s->last_done, stream));
+            late.wait.push_back(s->last_done);
+            if (!early.rows.empty()) groups->push_back(std::move(early));
+            for (auto& g : per_batch) groups->push_back(std::move(g));
+            if (!late.rows.empty()) groups->push_back(std::move(late));
+            s->last_stream = stream;
+            s->have_last = true;
+        }
+        return rc;
+    }
+    rc = capturing ? launch_lanes(s, p, n_lanes, stream) : launch_or_replay(s, p, n_lanes, stream, may_record);
     if (rc == MCRT_OK && !capturing) {
-        if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(s->last_done, stream));
         s->last_stream = stream;
         s->have_last = true;
@@ -478,7 +558,7 @@ namespace {
 void destroy_scene_now(mcrt_scene* s);
 
 size_t workspace_bytes(const mcrt_scene* s) {
-    size_t n = s->blob.bytes;
+    size_t n = s->blob.bytes + s->frame.bytes;
     for (const Lane& ln : s->lanes) {
         n += ln.tile_rng.bytes + ln.tile_draws.bytes + ln.scol.bytes + ln.end.bytes + ln.units.bytes + ln.unit_hits.bytes + ln.tile_mask.bytes;
         for (const auto& q : ln.queues) n += q.bytes;
@@ -580,12 +660,11 @@ size_t mcrt_scene_flatten(const mcrt_scene_desc* desc, void* blob, size_t capaci
     return b.size();
 }
 
-int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out) {
-    if (!out) return fail(MCRT_ERR_INVALID, "out is NULL");
+}  // extern "C"
+namespace {
+// uploads an already flattened scene to `device` (a pooled shell with its workspace when one is idle)
+int create_scene_from_blob(const std::vector<uint8_t>& b, int device, mcrt_scene** out) {
     *out = nullptr;
-    std::vector<uint8_t> b;
-    std::string err;
-    if (!flatten_scene(desc, b, err)) return fail(MCRT_ERR_INVALID, err);
     int n = mcrt_device_count();
     if (n <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(MCRT_ERR_NO_DEVICE, "device index out of range");
@@ -599,20 +678,27 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
     s->budget = 0;  // a budget halved under memory pressure is not inherited
     s->have_last = false;  // a pooled shell was synchronised when its previous owner let go of it
     s->last_stream = nullptr;
-    s->alpha_words = reinterpret_cast<const FlatHeader*>(b.data())->alpha_words;
-    s->n_meshes = reinterpret_cast<const FlatHeader*>(b.data())->n_meshes;
+    s->marks_used = 0;
+    const FlatHeader* fh = reinterpret_cast<const FlatHeader*>(b.data());
+    const FlatMesh* fm = reinterpret_cast<const FlatMesh*>(b.data() + fh->mesh_offset);
+    s->alpha_words = fh->alpha_words;
+    s->n_meshes = fh->n_meshes;
     s->posed = false;
-    {
-        const FlatHeader* fh = reinterpret_cast<const FlatHeader*>(b.data());
-        const FlatMesh* fm = reinterpret_cast<const FlatMesh*>(b.data() + fh->mesh_offset);
-        for (uint32_t i = 0; i < fh->n_meshes; ++i) s->posed = s->posed || (fm[i].flags & MESH_ROTATED) != 0;
-    }
-    {
-        const FlatHeader* fh = reinterpret_cast<const FlatHeader*>(b.data());
-        s->host_meshes.assign(b.begin(), b.begin() + fh->mesh_offset + sizeof(FlatMesh) * fh->n_meshes);
-    }
+    for (uint32_t i = 0; i < fh->n_meshes; ++i) s->posed = s->posed || (fm[i].flags & MESH_ROTATED) != 0;
+    s->host_meshes.assign(b.begin(), b.begin() + fh->mesh_offset + sizeof(FlatMesh) * fh->n_meshes);
     hipError_t e = s->blob.reserve(b.size());
-    if (e == hipSuccess) e = hipMemcpy(s->blob.ptr, b.data(), b.size(), hipMemcpyHostToDevice);
+    const size_t staging_need = b.size() + 64;  // the blob, then the lanes' flag words
+    if (e == hipSuccess && s->staging_bytes < staging_need) {
+        if (s->staging) (void)hipHostFree(s->staging);
+        s->staging = nullptr;
+        s->staging_bytes = 0;
+        e = hipHostMalloc(&s->staging, staging_need + (staging_need >> 2), hipHostMallocDefault);
+        if (e == hipSuccess) s->staging_bytes = staging_need + (staging_need >> 2);
+    }
+    if (e == hipSuccess) {
+        std::memcpy(s->staging, b.data(), b.size());
+        e = hipMemcpy(s->blob.ptr, s->staging, b.size(), hipMemcpyHostToDevice);
+    }
     for (int i = 0; i < 4 && e == hipSuccess; ++i)
         if (!s->ev[i]) e = hipEventCreate(&s->ev[i]);
     if (e != hipSuccess) {
@@ -621,6 +707,17 @@ int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out)
     }
     *out = s;
     return MCRT_OK;
+}
+}  // namespace
+extern "C" {
+
+int mcrt_scene_create(const mcrt_scene_desc* desc, int device, mcrt_scene** out) {
+    if (!out) return fail(MCRT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    std::vector<uint8_t> b;
+    std::string err;
+    if (!flatten_scene(desc, b, err)) return fail(MCRT_ERR_INVALID, err);
+    return create_scene_from_blob(b, device, out);
 }
 
 void mcrt_scene_destroy(mcrt_scene* s) {
@@ -660,6 +757,10 @@ void destroy_scene_now(mcrt_scene* s) {
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->last_done) (void)hipEventDestroy(s->last_done);
+    if (s->staging) (void)hipHostFree(s->staging);
+    if (s->main_stream) (void)hipStreamDestroy(s->main_stream);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    for (hipEvent_t m : s->marks) (void)hipEventDestroy(m);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     delete s;
@@ -671,11 +772,16 @@ int mcrt_scene_check(mcrt_scene* s) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     bool flagged = false;
+    uint32_t* flags = reinterpret_cast<uint32_t*>(static_cast<char*>(s->staging) + (s->staging_bytes - 64));  // pinned
+    int li = 0;
     for (Lane& ln : s->lanes) {
+        ++li;
         if (!ln.counters.ptr) continue;
         uint32_t* word = static_cast<uint32_t*>(ln.counters.ptr) + (kCounterWords - 1);
-        uint32_t flag = 0;
-        HIP_TRY(hipMemcpy(&flag, word, 4, hipMemcpyDeviceToHost));
+        uint32_t local = 0;
+        uint32_t* dst = s->staging ? &flags[li - 1] : &local;
+        HIP_TRY(hipMemcpy(dst, word, 4, hipMemcpyDeviceToHost));
+        const uint32_t flag = *dst;
         if (flag) {  // reported once: the word is cleared so that later renders (and the next owner of a pooled workspace) start clean
             flagged = true;
             HIP_TRY(hipMemset(word, 0, 4));
@@ -716,35 +822,25 @@ int mcrt_render_device_ex(mcrt_scene* s, const mcrt_config* cfg, int first, int 
     return enqueue_render(s, cfg, first, step, layout, d_out_f32, d_out_rgba8, static_cast<hipStream_t>(stream));
 }
 
-static int time_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, void* stream,
-                       int iters, float* avg_render_ms, float* avg_trace_kernel_ms, bool may_record);
-
 int mcrt_time_render_device(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out,
-                            void* stream, int iters, float* avg_render_ms, float* avg_trace_kernel_ms) {
-    return time_render(s, cfg, first, step, layout, d_out, stream, iters, avg_render_ms, avg_trace_kernel_ms, true);
-}
-
-static int time_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, void* stream,
-                       int iters, float* avg_render_ms, float* avg_trace_kernel_ms, bool may_record) {
+                            void* stream, int iters, float* avg_render_ms) {
     if (!s || !cfg || !d_out || iters < 1) return fail(MCRT_ERR_INVALID, "bad argument");
     if (!valid_frame(cfg)) return fail(MCRT_ERR_INVALID, "empty frame");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    double sum_render = 0.0, sum_kernel = 0.0;
+    double sum = 0.0;
     for (int i = 0; i < iters; ++i) {
-        // both figures bracket the whole pipeline of the frame (fork, every lane, join) on `stream`
+        // the events bracket the whole pipeline of the frame (fork, every lane, join) on `stream`
         HIP_TRY(hipEventRecord(s->ev[0], st));
-        int rc = enqueue_render(s, cfg, first, step, layout, d_out, nullptr, st, may_record);
+        int rc = enqueue_render(s, cfg, first, step, layout, d_out, nullptr, st);
         if (rc != MCRT_OK) return rc;
         HIP_TRY(hipEventRecord(s->ev[3], st));
         HIP_TRY(hipEventSynchronize(s->ev[3]));
         float a = 0;
         HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[3]));
-        sum_render += a;
-        sum_kernel += a;
+        sum += a;
     }
-    if (avg_render_ms) *avg_render_ms = static_cast<float>(sum_render / iters);
-    if (avg_trace_kernel_ms) *avg_trace_kernel_ms = static_cast<float>(sum_kernel / iters);
+    if (avg_render_ms) *avg_render_ms = static_cast<float>(sum / iters);
     return MCRT_OK;
 }
 
@@ -774,51 +870,250 @@ int mcrt_quantize_rgba8_device(const float* d_rgba, uint8_t* d_out, size_t n_pix
     return MCRT_OK;
 }
 
-int mcrt_render(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_rgba, mcrt_progress_fn progress,
-                void* user, int device) {
+}  // extern "C"
+namespace {
+
+int validate_config(const mcrt_config* cfg) {
+    if (cfg->max_bounces > kMaxBounces) return fail(MCRT_ERR_INVALID, "max_bounces above 4000 is not supported (one stack slot per level and sample)");
+    return MCRT_OK;
+}
+
+int one_shot_streams(mcrt_scene* s) {
+    if (!s->main_stream) HIP_TRY(hipStreamCreateWithFlags(&s->main_stream, hipStreamNonBlocking));
+    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    return MCRT_OK;
+}
+
+// pixel rows of tile row r of the frame
+int tile_row_height(const mcrt_config& c, int r) { return std::min(c.tile_size, c.height - r * c.tile_size); }
+
+// One rank of a host-buffer render: a scene shell on its device with the shard (rank, n_ranks) enqueued.
+struct HostRank {
+    mcrt_scene* scene = nullptr;
+    int device = 0;
+    std::vector<RowGroup> groups;
+};
+
+// Renders the frame on the given devices — rank r of N takes tile rows r, r+N, ... (cyclic: the figure sits in
+// the middle rows) on devices[r] — and assembles it in out_rgba.
+//   gather = 0: every device downloads its own rows straight into the host frame (N PCIe links in parallel,
+//               no device-to-device traffic); rows that are final early travel while the rest still renders.
+//   gather = 1: the ranks' packed rows go to devices[0] by peer copies (xGMI), one launch un-permutes them, one
+//               download brings the frame back.
+// Progress callbacks (exactly totalTiles, done = 1..total) fire on the calling thread as row groups land.
+int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_rgba, mcrt_progress_fn progress, void* user,
+                   const int* devices, int n_ranks, int gather) {
+    const double t0 = now_ms();
+    std::vector<uint8_t> blob;
+    std::string err;
+    if (!flatten_scene(desc, blob, err)) return fail(MCRT_ERR_INVALID, err);
+    const Shard all = make_shard(*cfg, 0, 1);
+    if (n_ranks > all.tiles_y) n_ranks = all.tiles_y;  // no more ranks than tile rows
+    if (n_ranks <= 1) gather = 0;
+    const int W = cfg->width, T = cfg->tile_size;
+    const size_t row_bytes = static_cast<size_t>(T) * W * 16;
+    const int total_tiles = all.tiles_x * all.tiles_y;
+    std::vector<HostRank> ranks(static_cast<size_t>(n_ranks));
+    int rc = MCRT_OK;
+    auto cleanup = [&](int code) {
+        for (HostRank& r : ranks)
+            if (r.scene) mcrt_scene_destroy(r.scene);  // synchronises, checks, pools the workspace
+        return code;
+    };
+    const double t1 = now_ms();
+    // ---- every rank: upload, enqueue its shard, note when which rows are final
+    for (int r = 0; r < n_ranks && rc == MCRT_OK; ++r) {
+        HostRank& hr = ranks[static_cast<size_t>(r)];
+        hr.device = devices[r];
+        rc = create_scene_from_blob(blob, hr.device, &hr.scene);
+        if (rc != MCRT_OK) break;
+        mcrt_scene* s = hr.scene;
+        // One lane: after a render that forked internal streams the runtime serves pageable copies from its staged
+        // path (1 MB chunks, ~15 GB/s: 2.3 ms per 1080p call instead of 0.8, tools/micro/hostpath.cpp), and
+        // for a host-buffer render the download, not the chain of kernels, is the longer part.
+        s->forced_lanes = 1;
+        rc = one_shot_streams(s);
+        if (rc != MCRT_OK) break;
+        const Shard mine = make_shard(*cfg, r, n_ranks);
+        const bool packed = n_ranks > 1;
+        const size_t frame_bytes = packed ? static_cast<size_t>(mine.owned_rows) * row_bytes : static_cast<size_t>(W) * cfg->height * 16;
+        size_t want = frame_bytes;
+        if (gather && r == 0)  // the root also holds every rank's packed rows and the assembled frame
+            want = static_cast<size_t>(n_ranks) * (static_cast<size_t>((all.tiles_y + n_ranks - 1) / n_ranks) * row_bytes) + static_cast<size_t>(W) * cfg->height * 16;
+        hipError_t e = s->frame.reserve(want);
+        if (e != hipSuccess) {
+            rc = hip_fail(e, "frame allocation");
+            break;
+        }
+        if (r == 0) (void)hipEventRecord(s->ev[0], s->main_stream);
+        rc = enqueue_render(s, cfg, r, n_ranks, packed ? MCRT_LAYOUT_PACKED : MCRT_LAYOUT_FRAME, static_cast<float*>(s->frame.ptr), nullptr,
+                            s->main_stream, /*may_record=*/false, &hr.groups);
+        if (rc == MCRT_OK && r == 0) (void)hipEventRecord(s->ev[3], s->main_stream);
+    }
+    if (rc != MCRT_OK) return cleanup(rc);
+    const double t2 = now_ms();
+    int done_tiles = 0;
+    auto report_rows = [&](const std::vector<int>& rows) {
+        if (!progress) return;
+        for (size_t i = 0; i < rows.size(); ++i)
+            for (int x = 0; x < all.tiles_x; ++x) progress(++done_tiles, total_tiles, user);
+    };
+    hipError_t e = hipSuccess;
+    if (!gather) {
+        // ---- downloads: a rank's row groups in completion order.  The host waits for a group's events, then
+        // copies on the (idle) copy stream; early groups travel while the GPU still renders the rest.  The
+        // runtime pins the caller's pages on first use and remembers them, so a caller that renders into the
+        // same buffer again gets 56 GB/s (0.6 ms for the 1080p frame; tools/micro/d2h.cpp).
+        auto download_group = [&](int r, size_t g) -> hipError_t {
+            HostRank& hr = ranks[static_cast<size_t>(r)];
+            mcrt_scene* s = hr.scene;
+            hipError_t ce = hipSetDevice(hr.device);
+            const RowGroup& grp = hr.groups[g];
+            for (size_t i = 0; i < grp.wait.size() && ce == hipSuccess; ++i) ce = hipEventSynchronize(grp.wait[i]);
+            const char* src0 = static_cast<const char*>(s->frame.ptr);
+            for (size_t i = 0; i < grp.rows.size() && ce == hipSuccess;) {
+                // a run of consecutive tile rows is one copy when the device buffer is the frame itself
+                size_t j = i + 1;
+                if (n_ranks == 1)
+                    while (j < grp.rows.size() && grp.rows[j] == grp.rows[j - 1] + 1) ++j;
+                const int row = grp.rows[i];
+                size_t bytes = 0;
+                for (size_t k = i; k < j; ++k) bytes += static_cast<size_t>(tile_row_height(*cfg, grp.rows[k])) * W * 16;
+                const size_t src_off = (n_ranks == 1 ? static_cast<size_t>(row) : static_cast<size_t>((row - r) / n_ranks)) * row_bytes;
+                ce = hipMemcpyAsync(reinterpret_cast<char*>(out_rgba) + static_cast<size_t>(row) * row_bytes, src0 + src_off, bytes,
+                                    hipMemcpyDeviceToHost, s->copy_stream);
+                i = j;
+            }
+            if (ce == hipSuccess) ce = hipStreamSynchronize(s->copy_stream);
+            return ce;
+        };
+        if (n_ranks == 1) {
+            for (size_t g = 0; g < ranks[0].groups.size() && e == hipSuccess; ++g) {
+                e = download_group(0, g);
+                if (e == hipSuccess) report_rows(ranks[0].groups[g].rows);
+            }
+        } else {
+            // one copier thread per rank (the PCIe links work in parallel); the calling thread delivers the progress calls
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<std::pair<int, size_t>> landed;  // (rank, group) in arrival order
+            int copiers_left = n_ranks;
+            hipError_t first_error = hipSuccess;
+            std::vector<std::thread> copiers;
+            for (int r = 0; r < n_ranks; ++r)
+                copiers.emplace_back([&, r] {
+                    hipError_t ce = hipSuccess;
+                    for (size_t g = 0; g < ranks[static_cast<size_t>(r)].groups.size() && ce == hipSuccess; ++g) {
+                        ce = download_group(r, g);
+                        if (ce == hipSuccess) {
+                            std::lock_guard<std::mutex> lock(mu);
+                            landed.emplace_back(r, g);
+                            cv.notify_one();
+                        }
+                    }
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (ce != hipSuccess && first_error == hipSuccess) first_error = ce;
+                    --copiers_left;
+                    cv.notify_one();
+                });
+            size_t reported = 0;
+            for (;;) {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return reported < landed.size() || copiers_left == 0; });
+                if (reported < landed.size()) {
+                    const std::pair<int, size_t> it = landed[reported++];
+                    lock.unlock();
+                    report_rows(ranks[static_cast<size_t>(it.first)].groups[it.second].rows);
+                } else {
+                    break;
+                }
+            }
+            for (std::thread& t : copiers) t.join();
+            e = first_error;
+        }
+    } else {
+        // ---- peer gather to the root device, one un-permuting launch, one download
+        mcrt_scene* root = ranks[0].scene;
+        const size_t rank_stride_px = static_cast<size_t>((all.tiles_y + n_ranks - 1) / n_ranks) * T * W;
+        char* gathered = static_cast<char*>(root->frame.ptr);  // rank 0 rendered into slot 0 already
+        float* assembled = reinterpret_cast<float*>(gathered + static_cast<size_t>(n_ranks) * rank_stride_px * 16);
+        for (int r = 1; r < n_ranks && e == hipSuccess; ++r) {
+            HostRank& hr = ranks[static_cast<size_t>(r)];
+            e = hipSetDevice(hr.device);
+            const Shard mine = make_shard(*cfg, r, n_ranks);
+            // behind the rank's render, on the rank's stream: its packed rows to the root's slot r
+            if (e == hipSuccess)
+                e = hipMemcpyPeerAsync(gathered + static_cast<size_t>(r) * rank_stride_px * 16, ranks[0].device, hr.scene->frame.ptr, hr.device,
+                                       static_cast<size_t>(mine.owned_rows) * row_bytes, hr.scene->main_stream);
+            hipEvent_t sent = next_mark(hr.scene);
+            if (e == hipSuccess && !sent) e = hipErrorOutOfMemory;
+            if (e == hipSuccess) e = hipEventRecord(sent, hr.scene->main_stream);
+            if (e == hipSuccess) e = hipSetDevice(ranks[0].device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(root->main_stream, sent, 0);
+        }
+        if (e == hipSuccess) e = hipSetDevice(ranks[0].device);
+        if (e == hipSuccess) e = launch_assemble_frame(*cfg, n_ranks, reinterpret_cast<const float*>(gathered), rank_stride_px, assembled, root->main_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_rgba, assembled, static_cast<size_t>(W) * cfg->height * 16, hipMemcpyDeviceToHost, root->main_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(root->main_stream);
+        if (e == hipSuccess && progress)
+            for (int d = 1; d <= total_tiles; ++d) progress(d, total_tiles, user);
+    }
+    if (e != hipSuccess) return cleanup(hip_fail(e, "frame download"));
+    const double t3 = now_ms();
+    float kernel_ms = 0.0f;
+    (void)hipSetDevice(ranks[0].device);
+    (void)hipEventElapsedTime(&kernel_ms, ranks[0].scene->ev[0], ranks[0].scene->ev[3]);
+    for (HostRank& hr : ranks) {
+        const int c = mcrt_scene_check(hr.scene);
+        if (c != MCRT_OK) rc = c;
+    }
+    cleanup(rc);
+    if (rc != MCRT_OK) return rc;
+    g_timings.flatten_ms = static_cast<float>(t1 - t0);
+    g_timings.h2d_ms = static_cast<float>(t2 - t1);  // uploads, workspace checks and every launch call
+    g_timings.kernel_ms = kernel_ms;                  // rank 0's pipeline on the device (hipEvents)
+    g_timings.d2h_ms = static_cast<float>(t3 - t2);   // from the last launch call until the last row has landed (overlaps the render)
+    g_timings.total_ms = static_cast<float>(now_ms() - t0);
+    return MCRT_OK;
+}
+
+}  // namespace
+extern "C" {
+
+int mcrt_render_multi(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_rgba, mcrt_progress_fn progress,
+                      void* user, const int* devices, int n_devices, int gather) {
     if (!desc || !cfg) return fail(MCRT_ERR_INVALID, "NULL argument");
     if (!valid_frame(cfg)) return MCRT_OK;  // generateTiles → empty → untouched Image (tile_renderer.cpp:144-146)
     if (!out_rgba) return fail(MCRT_ERR_INVALID, "out_rgba is NULL");
-    double t0 = now_ms();
-    mcrt_scene* s = nullptr;
-    int rc = mcrt_scene_create(desc, device, &s);
-    if (rc != MCRT_OK) return rc;
-    double t1 = now_ms();
-    const size_t npix = static_cast<size_t>(cfg->width) * cfg->height;
-    DeviceBuffer frame;
-    hipError_t e = frame.reserve(npix * 16);
-    if (e != hipSuccess) {
-        mcrt_scene_destroy(s);
-        return hip_fail(e, "frame allocation");
+    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
+    const int visible = mcrt_device_count();
+    if (visible <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    std::vector<int> all;
+    if (!devices || n_devices <= 0) {  // every visible device
+        for (int d = 0; d < visible; ++d) all.push_back(d);
+        devices = all.data();
+        n_devices = visible;
     }
-    float kernel_ms = 0.0f, render_ms = 0.0f;
-    rc = time_render(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, static_cast<float*>(frame.ptr), nullptr, 1, &render_ms, &kernel_ms,
-                     /*may_record=*/false);
-    if (rc == MCRT_OK) rc = mcrt_scene_check(s);
-    double t2 = now_ms();
-    if (rc == MCRT_OK) {
-        e = hipMemcpy(out_rgba, frame.ptr, npix * 16, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "frame download");
-    }
-    double t3 = now_ms();
-    frame.release();
-    mcrt_scene_destroy(s);
-    if (rc != MCRT_OK) return rc;
-    if (progress) {  // exactly totalTiles calls, done = 1..total (tile_renderer.cpp:168-172)
-        int total = mcrt_generate_tiles(cfg->width, cfg->height, cfg->tile_size, nullptr, 0);
-        for (int d = 1; d <= total; ++d) progress(d, total, user);
-    }
-    g_timings.flatten_ms = static_cast<float>(t1 - t0);
-    g_timings.h2d_ms = 0.0f;  // folded into flatten_ms (one 10-60 KB copy)
-    g_timings.kernel_ms = kernel_ms;
-    g_timings.d2h_ms = static_cast<float>(t3 - t2);
-    g_timings.total_ms = static_cast<float>(now_ms() - t0);
-    return MCRT_OK;
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= visible) return fail(MCRT_ERR_NO_DEVICE, "device index out of range");
+    return render_to_host(desc, cfg, out_rgba, progress, user, devices, n_devices, gather ? 1 : 0);
+}
+
+int mcrt_render(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_rgba, mcrt_progress_fn progress,
+                void* user, int device) {
+    if (device == MCRT_DEVICE_ALL) return mcrt_render_multi(desc, cfg, out_rgba, progress, user, nullptr, 0, 0);
+    if (!desc || !cfg) return fail(MCRT_ERR_INVALID, "NULL argument");
+    if (!valid_frame(cfg)) return MCRT_OK;  // generateTiles → empty → untouched Image (tile_renderer.cpp:144-146)
+    if (!out_rgba) return fail(MCRT_ERR_INVALID, "out_rgba is NULL");
+    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
+    if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    return render_to_host(desc, cfg, out_rgba, progress, user, &device, 1, 0);
 }
 
 int mcrt_render_tile(const mcrt_scene_desc* desc, const mcrt_config* cfg, int tile_index, float* frame_rgba, int device) {
     if (!desc || !cfg || !frame_rgba) return fail(MCRT_ERR_INVALID, "NULL argument");
     if (!valid_frame(cfg)) return MCRT_OK;
+    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
     Shard all = make_shard(*cfg, 0, 1);
     if (tile_index < 0 || tile_index >= all.tiles_x * all.tiles_y) return fail(MCRT_ERR_INVALID, "tile index out of range");
     const int row = tile_index / all.tiles_x, col = tile_index % all.tiles_x;
@@ -826,21 +1121,20 @@ int mcrt_render_tile(const mcrt_scene_desc* desc, const mcrt_config* cfg, int ti
     int rc = mcrt_scene_create(desc, device, &s);
     if (rc != MCRT_OK) return rc;
     // render the tile row that contains the tile (a shard of exactly one row), packed
-    const size_t row_floats = static_cast<size_t>(cfg->tile_size) * cfg->width * 4;
-    DeviceBuffer band;
+    const int th = tile_row_height(*cfg, row);
+    const size_t row_floats = static_cast<size_t>(th) * cfg->width * 4;
     std::vector<float> host(row_floats);
-    hipError_t e = band.reserve(row_floats * 4);
+    hipError_t e = s->frame.reserve(static_cast<size_t>(cfg->tile_size) * cfg->width * 16);
     if (e == hipSuccess) {
-        rc = enqueue_render(s, cfg, row, all.tiles_y, MCRT_LAYOUT_PACKED, static_cast<float*>(band.ptr), nullptr, nullptr, /*may_record=*/false);
+        rc = enqueue_render(s, cfg, row, all.tiles_y, MCRT_LAYOUT_PACKED, static_cast<float*>(s->frame.ptr), nullptr, nullptr, /*may_record=*/false);
         if (rc == MCRT_OK) rc = mcrt_scene_check(s);
-        if (rc == MCRT_OK) e = hipMemcpy(host.data(), band.ptr, row_floats * 4, hipMemcpyDeviceToHost);
+        if (rc == MCRT_OK) e = hipMemcpy(host.data(), s->frame.ptr, row_floats * 4, hipMemcpyDeviceToHost);
     }
-    band.release();
     mcrt_scene_destroy(s);
     if (e != hipSuccess) return hip_fail(e, "render_tile");
     if (rc != MCRT_OK) return rc;
     const int x0 = col * cfg->tile_size, y0 = row * cfg->tile_size;
-    const int tw = std::min(cfg->tile_size, cfg->width - x0), th = std::min(cfg->tile_size, cfg->height - y0);
+    const int tw = std::min(cfg->tile_size, cfg->width - x0);
     for (int ly = 0; ly < th; ++ly)
         std::memcpy(frame_rgba + 4 * (static_cast<size_t>(y0 + ly) * cfg->width + x0),
                     host.data() + 4 * (static_cast<size_t>(ly) * cfg->width + x0), static_cast<size_t>(tw) * 16);
@@ -851,19 +1145,18 @@ int mcrt_render_tile(const mcrt_scene_desc* desc, const mcrt_config* cfg, int ti
 int mcrt_render_png(const mcrt_scene_desc* desc, const mcrt_config* cfg, const char* path, int device) {
     if (!desc || !cfg || !path) return fail(MCRT_ERR_INVALID, "NULL argument");
     if (!valid_frame(cfg)) return fail(MCRT_ERR_INVALID, "empty image");
+    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
     mcrt_scene* s = nullptr;
     int rc = mcrt_scene_create(desc, device, &s);
     if (rc != MCRT_OK) return rc;
     const size_t npix = static_cast<size_t>(cfg->width) * cfg->height;
-    DeviceBuffer plane;
     std::vector<uint8_t> host(npix * 4);
-    hipError_t e = plane.reserve(npix * 4);
+    hipError_t e = s->frame.reserve(npix * 4);
     if (e == hipSuccess) {
-        rc = enqueue_render(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, nullptr, static_cast<uint8_t*>(plane.ptr), nullptr, /*may_record=*/false);
+        rc = enqueue_render(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, nullptr, static_cast<uint8_t*>(s->frame.ptr), nullptr, /*may_record=*/false);
         if (rc == MCRT_OK) rc = mcrt_scene_check(s);
-        if (rc == MCRT_OK) e = hipMemcpy(host.data(), plane.ptr, npix * 4, hipMemcpyDeviceToHost);
+        if (rc == MCRT_OK) e = hipMemcpy(host.data(), s->frame.ptr, npix * 4, hipMemcpyDeviceToHost);
     }
-    plane.release();
     mcrt_scene_destroy(s);
     if (e != hipSuccess) return hip_fail(e, "render_png");
     if (rc != MCRT_OK) return rc;

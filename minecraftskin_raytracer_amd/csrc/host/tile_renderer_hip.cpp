@@ -11,11 +11,15 @@
 //   :129-189 render: returns Image(W,H); never throws for render failures — the message is kept in
 //            lastErrors() as TileError{-1, msg} and the pixels stay Color() = (0,0,0,1);
 //            progressCallback called exactly totalTiles times (done = 1..total) — here from the
-//            calling thread after the frame is back, there is no per-tile host round trip;
+//            calling thread, for each group of tile rows once it has landed in the Image (rows that
+//            hold only background right after the first kernel, the others when the render is done;
+//            pass by pass for frames that take several);
 //            config.threadCount is accepted and ignored; config.tileSize is honoured (it seeds the
 //            per-tile RNG streams)
 //   :71-127  renderTile: one tile into an existing Image
-// The device is chosen with the environment variable MCRT_DEVICE (default 0).
+// The device is chosen with the environment variable MCRT_DEVICE: an index (default 0) or "all" — every
+// visible device renders its cyclic share of the tile rows and downloads it straight into the Image
+// (mcrt_render_multi; MCRT_GATHER=1 assembles on the first device by peer copies instead).
 #ifdef MCRT_USE_REFERENCE_HEADERS
 #include "raytracer/tile_renderer.h"
 #else
@@ -33,6 +37,11 @@ std::vector<TileRenderer::TileError> TileRenderer::errors_;
 namespace {
 int chosen_device() {
     const char* e = std::getenv("MCRT_DEVICE");
+    if (e && std::strcmp(e, "all") == 0) return MCRT_DEVICE_ALL;
+    return e ? std::atoi(e) : 0;
+}
+int chosen_gather() {
+    const char* e = std::getenv("MCRT_GATHER");
     return e ? std::atoi(e) : 0;
 }
 void progress_trampoline(int done, int total, void* user) {
@@ -59,9 +68,12 @@ Image TileRenderer::render(const Scene& scene, const RayTracer::Config& config,
 
     mcrt_adapter::SceneDescription desc(scene);
     mcrt_config cfg = mcrt_adapter::to_mcrt_config(config);
-    int rc = mcrt_render(desc.get(), &cfg, reinterpret_cast<float*>(output.pixels.data()),
-                         progressCallback ? progress_trampoline : nullptr, progressCallback ? &progressCallback : nullptr,
-                         chosen_device());
+    const int device = chosen_device();
+    float* pixels = reinterpret_cast<float*>(output.pixels.data());
+    mcrt_progress_fn cb = progressCallback ? progress_trampoline : nullptr;
+    void* user = progressCallback ? &progressCallback : nullptr;
+    int rc = device == MCRT_DEVICE_ALL ? mcrt_render_multi(desc.get(), &cfg, pixels, cb, user, nullptr, 0, chosen_gather())
+                                       : mcrt_render(desc.get(), &cfg, pixels, cb, user, device);
     if (rc != MCRT_OK) {
         errors_.push_back({-1, mcrt_last_error()});
         for (Color& c : output.pixels) c = Color();
@@ -79,7 +91,8 @@ void TileRenderer::renderTile(const Tile& tile, const Scene& scene, const RayTra
     int index = (tile.y / config.tileSize) * cols + tile.x / config.tileSize;
     mcrt_adapter::SceneDescription desc(scene);
     mcrt_config cfg = mcrt_adapter::to_mcrt_config(config);
-    if (mcrt_render_tile(desc.get(), &cfg, index, reinterpret_cast<float*>(output.pixels.data()), chosen_device()) != MCRT_OK)
+    const int device = chosen_device() == MCRT_DEVICE_ALL ? 0 : chosen_device();
+    if (mcrt_render_tile(desc.get(), &cfg, index, reinterpret_cast<float*>(output.pixels.data()), device) != MCRT_OK)
         errors_.push_back({index, mcrt_last_error()});
 }
 

@@ -100,7 +100,16 @@ constexpr int kCounterWords = 4096;
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream);
 // enqueue the whole pipeline of one lane on `stream` (p.tile_rng already seeded): per batch of tile rows
 // plan → primary → bounce → chase → light_samples → shadow → (ao_dirs → ao →) shade → resolve
-hipError_t launch_render(const RenderParams& p, hipStream_t stream);
+// Optional events for a caller that downloads tile rows as they become final (the one-shot host path):
+//  after_plan    recorded behind the first pass's plan_tiles: with bg_in_plan every tile row that holds no touched
+//                tile is complete then
+//  batch_done[b] recorded behind pass b's resolve: the rows of that pass are complete (n_batch_done entries, may be 0)
+struct LaunchMarks {
+    hipEvent_t after_plan = nullptr;
+    hipEvent_t* batch_done = nullptr;
+    int n_batch_done = 0;
+};
+hipError_t launch_render(const RenderParams& p, hipStream_t stream, const LaunchMarks* marks = nullptr);
 
 hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const float* packed, float* frame,
                               hipStream_t stream);

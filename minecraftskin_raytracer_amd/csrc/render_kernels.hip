@@ -344,7 +344,6 @@ struct TilePlan {
 };
 __device__ __forceinline__ TilePlan plan_tile(const SceneView& sc, const RenderParams& p, const TileGeom& tg, int tile, int lane) {
     const mcrt_config& cfg = p.cfg;
-    const WaveSpace& ws = p.ws;
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
     const bool cull = sc.hdr->cull_ok != 0 && sc.n_meshes < 64;
     const float aspect = static_cast<float>(cfg.width) / static_cast<float>(cfg.height);
@@ -1471,7 +1470,7 @@ hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
+hipError_t launch_render(const RenderParams& p, hipStream_t stream, const LaunchMarks* marks) {
     const int n = owned_tiles(p);
     if (n <= 0) return hipSuccess;
     const size_t dyn = p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_face_entries / 6) * kMeshTabWords * 4 +
@@ -1489,6 +1488,10 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
                            p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
+        if (marks && marks->after_plan && r0 == 0) {
+            e = hipEventRecord(marks->after_plan, stream);
+            if (e != hipSuccess) return e;
+        }
         const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
         if (p.scene_in_lds && !p.scene_posed) {
             hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
@@ -1502,6 +1505,11 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream) {
         }
         const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
         hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, p.scene, out, out8, p);
+        const int batch = r0 / p.rows_per_batch;
+        if (marks && batch < marks->n_batch_done) {
+            e = hipEventRecord(marks->batch_done[batch], stream);
+            if (e != hipSuccess) return e;
+        }
     }
     return hipGetLastError();
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(mcrt):
     for name in declared:
         assert hasattr(lib, name), f"libmcrt.so does not export {name}"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert lib.mcrt_abi_version() == 1
+    assert lib.mcrt_abi_version() == 2
 
 
 def test_struct_layouts_match_header_sizes():
@@ -207,3 +207,23 @@ def test_synthetic_skin_is_deterministic(mcrt):
     assert a[0, 0].tolist() == [5, 4, 139, 255]  # first three LCG steps from seed 12345, >> 24
     assert (a[16:32, :, 3] == 255).all() and 0.25 < (a[32:48, :, 3] == 255).mean() < 0.5
     assert mcrt.synthetic_skin("S32").shape == (32, 64, 4)
+
+
+def test_bounce_limit_is_checked_before_any_device_work(mcrt):
+    """max_bounces above 4000 is refused with MCRT_ERR_INVALID (one stack slot per level and sample; the
+    reference itself stops at the first miss, raytracer.cpp:94-102) — by every host-buffer entry point,
+    before a device is touched."""
+    import ctypes as C
+
+    import scenes
+    from minecraftskin_raytracer_amd import _lib
+
+    lib = _lib.load()
+    sd = scenes.skin_scene("S64", 0)
+    cfg = abi.Config(width=16, height=16, maxBounces=4001).to_c()
+    out = np.zeros((16, 16, 4), np.float32)
+    assert lib.mcrt_render(sd.ptr, C.byref(cfg), abi.fptr(out), C.cast(None, abi.PROGRESS_FN), None, 0) == abi.MCRT_ERR_INVALID
+    assert b"4000" in lib.mcrt_last_error()
+    assert lib.mcrt_render_multi(sd.ptr, C.byref(cfg), abi.fptr(out), C.cast(None, abi.PROGRESS_FN), None, None, 0, 0) == abi.MCRT_ERR_INVALID
+    assert lib.mcrt_render_tile(sd.ptr, C.byref(cfg), 0, abi.fptr(out), 0) == abi.MCRT_ERR_INVALID
+    assert lib.mcrt_render_png(sd.ptr, C.byref(cfg), b"/tmp/never_written.png", 0) == abi.MCRT_ERR_INVALID

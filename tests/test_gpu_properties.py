@@ -95,6 +95,40 @@ def test_4k_b8_spp16_sampled_tiles_match_oracle(mcrt, oracle, gpu):
         scenes.assert_bit_equal(f[y:y + h, x:x + w], scratch[y:y + h, x:x + w], f"tile {i}")
 
 
+def test_4k_b4_spp4_sampled_tiles_and_8_way_shards(mcrt, oracle, gpu):
+    # BASELINE.json configs[3]: 3840x2160, 4 bounces, 4 spp, tile rows sharded 8 ways (68 tile rows, the last
+    # clipped to 16 px) — at full size: sampled tiles against the oracle's renderTile, and the 8 ranks' packed
+    # shards re-assembled by the gather root's launch equal the whole-frame render
+    sd = scenes.skin_scene("S64", 0)
+    ds = mcrt.DeviceScene(sd)
+    cfg = abi.Config(width=3840, height=2160, maxBounces=4, samplesPerPixel=4)
+    frame = render_dev(mcrt, ds, cfg)
+    f = frame.cpu().numpy()
+    tiles = oracle.generate_tiles(cfg.width, cfg.height, cfg.tileSize)
+    assert len(tiles) == 120 * 68 and tiles[-1][3] == 16
+    bgdiff = np.abs(f[..., :3] - f[0, 0, :3]).sum(axis=2) > 0.2
+    weight = [bgdiff[y:y + h, x:x + w].sum() for x, y, w, h in tiles]
+    scratch = np.zeros_like(f)
+    for i in list(np.argsort(weight)[-4:]) + [0, 119, len(tiles) - 1, len(tiles) - 120, 4000]:
+        oracle.render_tile(sd.ptr, cfg, tiles[i], scratch)
+        x, y, w, h = tiles[i]
+        scenes.assert_bit_equal(f[y:y + h, x:x + w], scratch[y:y + h, x:x + w], f"tile {i} {tiles[i]}")
+    from minecraftskin_raytracer_amd import parallel
+
+    world = 8
+    rows = parallel.packed_rows(cfg, world)
+    st = torch.cuda.current_stream().cuda_stream
+    gathered = torch.full((world, rows, cfg.width, 4), -3.0, dtype=torch.float32, device="cuda")
+    for r in range(world):
+        ds.render_device(cfg, gathered[r].data_ptr(), r, world, abi.LAYOUT_PACKED, st)
+    rebuilt = torch.zeros_like(frame)
+    mcrt.assemble_frame_device(cfg, world, gathered.data_ptr(), rows * cfg.width, rebuilt.data_ptr(), st)
+    torch.cuda.synchronize()
+    ds.check()
+    assert torch.equal(rebuilt, frame)
+    ds.close()
+
+
 def test_8k_legacy_skin_band_matches_oracle(mcrt, oracle, gpu):
     # BASELINE.json configs[4] geometry (7680x4320, 8 bounces, 64 spp, legacy skin, single reference
     # light) on one owned tile row of an 8-way shard; oracle on two tiles of it

@@ -12,7 +12,7 @@ def t(scene_desc, iters=5, **kw):
     ds = M.DeviceScene(scene_desc)
     frame = torch.empty((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda")
     ds.time_render_device(cfg, frame.data_ptr(), 2)
-    r, k = ds.time_render_device(cfg, frame.data_ptr(), iters)
+    r = k = ds.time_render_device(cfg, frame.data_ptr(), iters)
     ds.close()
     return round(r, 4), round(k, 4)
 
