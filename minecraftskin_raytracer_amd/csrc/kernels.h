@@ -77,7 +77,7 @@ struct RenderParams {
     int scene_posed;       // 1 when any mesh has a rotation (selects the kernels that carry the local-frame path)
     int rows_per_batch;    // owned tile rows per pipeline pass
     int bg_in_plan;        // 1: `plan_tiles` renders the background tiles from the draws in LDS and only touched tiles' draws
-                           //    go to HBM; 0 (a pixel's draws exceed one mt19937 twist): all streams to HBM, `primary` renders them
+                           //    go to HBM; 0 (more than 24 draws per pixel): all streams to HBM, `primary` renders them
     int flat;              // 1: flat pipeline (all levels' records shaded at once); 0: general variants, one launch set per level
 };
 

@@ -116,8 +116,9 @@ __device__ __forceinline__ void store_pixel(float4* __restrict__ out_frame, ucha
 //    draws are complete (they lie in the new 624 words and the previous 624, both still in LDS) get
 //    their gradient samples, the ordered sample sum (tile_renderer.cpp:111-124) and a coalesced store.
 //    Writing those streams out and reading them back in `primary` was 134 MB of the frame's HBM traffic.
-//    Needs a pixel's draws to fit one twist (spp * draws per sample <= 624: RenderParams::bg_in_plan);
-//    otherwise every tile's stream goes to HBM and `primary` renders the background tiles.
+//    Pays while a twist completes enough pixels to fill the wave's lanes (spp * draws per sample <= 24:
+//    RenderParams::bg_in_plan); at higher sample counts every tile's stream goes to HBM and `primary`
+//    renders the background tiles with a thread per pixel.
 // (Generating the stream inside `primary` with block-wide twists made that kernel barrier-bound: 3
 // barriers per 624 draws, ~60 us of the 1080p / 4 spp frame, milliseconds at 64 spp.)
 // ---------------------------------------------------------------------------------------------
@@ -207,14 +208,23 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
                 if (e < m) dst[done + e] = mt_to_unit(mt_temper(n[e]));
             }
         } else {
-            // draws [done, done + m) are in n, the 624 before them in o (the previous twist's words)
+            // draws [done, done + m) are in n, the 624 before them in o (the previous twist's words).  Pixels
+            // go in whole rounds of 64 (a twist completes only 624 / (2 spp) of them — 78 at 4 spp — and a
+            // partial round costs as much as a full one); the rest waits for the next twist, except those
+            // whose draws reach back into o, which that twist overwrites.
             const unsigned complete = static_cast<unsigned>((done + static_cast<unsigned long long>(m)) / per_pixel);
-            background_pixels(sc, p, tg, out_frame, out8, pixels_done, complete, lane, [&](unsigned long long g) __attribute__((always_inline)) {
-                const uint32_t raw = (g >= done) ? n[g - done] : o[g + 624ull - done];
-                return mt_to_unit(mt_temper(raw));
-            });
-            pixels_done = complete;
-            wave_sync();  // the next twist overwrites o
+            const unsigned must_end = min(complete, static_cast<unsigned>((done + per_pixel - 1ull) / per_pixel));  // first draw before `done`
+            const unsigned pending = complete - pixels_done;
+            unsigned take = (done + 624ull >= total) ? pending : (pending / 64u) * 64u;
+            if (pixels_done + take < must_end) take = must_end - pixels_done;
+            if (take > 0u) {
+                background_pixels(sc, p, tg, out_frame, out8, pixels_done, pixels_done + take, lane, [&](unsigned long long g) __attribute__((always_inline)) {
+                    const uint32_t raw = (g >= done) ? n[g - done] : o[g + 624ull - done];
+                    return mt_to_unit(mt_temper(raw));
+                });
+                pixels_done += take;
+                wave_sync();  // the next twist overwrites o
+            }
         }
     }
 }
@@ -1375,9 +1385,10 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
         return mx;
     };
     // the tiles' jitter / lens draws: of the touched tiles only when `plan_tiles` renders the background tiles
-    // itself (a pixel's draws fit one 624-word twist), of every tile of the batch otherwise
+    // itself (few draws per pixel: a 624-word twist then completes >= 26 pixels, enough for whole rounds of
+    // the wave's 64 lanes), of every tile of the batch otherwise
     const size_t draws_stride = tile_slots * static_cast<size_t>(p.draws_per_sample);
-    p.bg_in_plan = spp * static_cast<size_t>(p.draws_per_sample) <= 624 ? 1 : 0;
+    p.bg_in_plan = spp * static_cast<size_t>(p.draws_per_sample) <= 24 ? 1 : 0;
     const size_t draws_row_bytes = p.bg_in_plan ? 0 : draws_stride * 4 * static_cast<size_t>(p.shard.tiles_x);
     const size_t draws_tile_bytes = p.bg_in_plan ? draws_stride * 4 : 0;
     p.ws.draws_stride = static_cast<uint32_t>(draws_stride > 0xffffffffull ? 0xffffffffull : draws_stride);
