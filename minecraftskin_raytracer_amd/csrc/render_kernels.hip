@@ -927,6 +927,105 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// lit (flat pipeline): light samples AND shadow rays of every record in one launch, handed over through
+// LDS.  Per block of up to `lit_round` records:
+//   phase A  a lane per record — the 397-step mt19937 seeding recurrence, the 2·S draws, the S disk
+//            sample positions and the record's bundle mask (shading.cpp:28-53) — into LDS;
+//   phase B  a lane per (record, light sample) — the exact any-hit test on the bundle mask — lit
+//            count by ballot (S a power of two) or LDS atomics.
+// As two kernels the positions and masks went through HBM (96 + 8 B written and read back per
+// record: ~180 MB of the metric frame's counted traffic), and the VALU-bound seeding chains could not
+// overlap the latency-bound shadow rays.  Hard shadows / a point light: phase B alone, one ray per record.
+// ---------------------------------------------------------------------------------------------
+#ifndef MCRT_LIT_WAVES
+#define MCRT_LIT_WAVES 4
+#endif
+template <int kView>
+__global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];  // [scene tables][masks][positions: lit_round x S x 3 floats][lit counts]
+    const SceneView scg = view_of(scene_blob);
+    const WaveSpace& ws = p.ws;
+    const Scope scope{0, 1};
+    if (no_entry_blocks(ws, scope)) return;  // before the collective staging
+    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
+    constexpr bool kPosed = kView != kViewLdsUnposed;
+    const int mode = shadow_mode(scg, p.cfg);
+    const int S = p.cfg.shadow_samples;
+    const uint32_t pairs_per_hit = (mode == SHADOW_SOFT) ? static_cast<uint32_t>(S) : 1u;
+    const bool pow2 = (pairs_per_hit & (pairs_per_hit - 1u)) == 0u && pairs_per_hit <= 64u;
+    const uint32_t round = static_cast<uint32_t>(p.lit_round);
+    unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_dyn + p.lit_lds_offset);  // 16-aligned
+    float* s_pos = reinterpret_cast<float*>(s_cand + round);
+    uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + static_cast<size_t>(round) * pairs_per_hit * 3);
+    uint32_t* lit = ws.lit[0];
+    const V3 lpos = ld3(scg.hdr->light_pos);
+    const float lradius = scg.hdr->light_radius;
+    const uint32_t lane = threadIdx.x & 63u;
+    for_each_entry_block(ws, scope, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+        for (uint32_t r0 = 0; r0 < n; r0 += round) {  // uniform
+            const uint32_t m = min(round, n - r0);
+            const uint32_t base = first + r0;
+            // ---- phase A: a lane per record
+            if (threadIdx.x < m) {
+                if (!pow2) s_lit[threadIdx.x] = 0u;
+                if (mode == SHADOW_SOFT) {
+                    const uint32_t e = base + threadIdx.x;
+                    const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
+                    const V3 P = mk(hp.x, hp.y, hp.z), N = mk(hn.x, hn.y, hn.z);
+                    MtShort rng;
+                    rng.seed(shadow_seed(P, __float_as_int(ws.q_d[0][e].w)));
+                    s_cand[threadIdx.x] = bundle_candidates<kPosed>(scg, P + N * 1e-3f, lpos, lradius);
+                    const LightFrame frame = light_frame(scg, P);
+                    float* dst = s_pos + static_cast<size_t>(threadIdx.x) * 3 * S;
+                    for (int i = 0; i < S; ++i) {
+                        const float d0 = rng.uniform();
+                        const float d1 = rng.uniform();
+                        const V3 t = light_sample_on_frame(scg, frame, d0, d1);
+                        dst[3 * i + 0] = t.x;
+                        dst[3 * i + 1] = t.y;
+                        dst[3 * i + 2] = t.z;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- phase B: a lane per (record, light sample); every lane of a wave runs the same number of turns (ballot inside)
+            const uint32_t total = m * pairs_per_hit;
+            for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) {
+                const uint32_t q = q0 + lane;
+                bool visible = false;
+                uint32_t k = 0;
+                if (q < total) {
+                    k = q / pairs_per_hit;
+                    const uint32_t e = base + k;
+                    const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
+                    const V3 P = mk(hp.x, hp.y, hp.z);
+                    V3 N = mk(hn.x, hn.y, hn.z);
+                    if (mode == SHADOW_HARD) N = normalize(N);
+                    if (mode == SHADOW_SOFT)
+                        visible = !in_shadow_masked(sc, P, N, ld3(s_pos + static_cast<size_t>(q) * 3), s_cand[k]);
+                    else
+                        visible = !in_shadow_inline(sc, P, N, lpos);
+                }
+                if (pow2) {
+                    const unsigned long long bal = __ballot(visible);
+                    if (q < total && (lane & (pairs_per_hit - 1u)) == 0u) {
+                        const unsigned long long grp = (pairs_per_hit == 64u) ? bal : ((bal >> lane) & ((1ull << pairs_per_hit) - 1ull));
+                        lit[base + k] = static_cast<uint32_t>(__popcll(grp));
+                    }
+                } else if (visible) {
+                    atomicAdd(&s_lit[k], 1u);
+                }
+            }
+            __syncthreads();  // the next round overwrites the positions
+            if (!pow2) {
+                if (threadIdx.x < m) lit[base + threadIdx.x] = s_lit[threadIdx.x];
+                __syncthreads();
+            }
+        }
+    });
+}
+
 // ambient occlusion (raytracer.cpp:38-78, depth 0 only) as two stages over the primary hits:
 // ao_dirs — lane per hit: tangent frame, mt19937(ao seed), the A cosine-weighted directions, stored
 // where the (now consumed) light samples of the primary hits were; ao — lane per (hit, direction): any hit
@@ -1327,12 +1426,19 @@ Shard make_shard(const mcrt_config& cfg, int first, int step) {
     return s;
 }
 
+// dynamic LDS of the scene tables a kernel stages (stage_tables): face table, mesh table, alpha predicates
+static size_t scene_table_bytes(const RenderParams& p) {
+    return p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_face_entries / 6) * kMeshTabWords * 4 +
+                                static_cast<size_t>(p.lds_alpha_words) * 4
+                          : 0;
+}
 static int owned_tiles(const RenderParams& p) { return p.shard.owned_rows * p.shard.tiles_x; }
 static bool soft_sampling(const mcrt_config& c) { return c.soft_shadows && c.shadow_samples > 1; }
 
 // The flat pipeline keeps the records of every level at once: its arrays are laid out for up to
 // kFlatMaxBounces reflection levels (1 + maxBounces records per sample slot in the worst case).
 constexpr int kFlatMaxBounces = 8;
+constexpr size_t kLitLdsBytes = 32 * 1024;  // `lit`: LDS for the sample positions, masks and counts of a round of records
 // rare features that need the general kernel variants (one launch set per level, ping-pong queues): per-hit RNG
 // streams longer than the register-only engine covers (they run AO inside `level_shade`, sequentially), or
 // more bounces than the flat record arrays are laid out for
@@ -1371,7 +1477,21 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     // records per slot: flat — the primary hit and one per reflection level; general — two ping-pong queues
     const size_t recs = p.flat ? static_cast<size_t>(1 + (c.max_bounces > 0 ? c.max_bounces : 0)) : 2;
     // bytes per slot: colour + end code, per record 5 float4 + light samples + mask + lit, AO counts, stack
-    const size_t per_entry = 16 + 4 + recs * (5 * 16 + 12 * rays + (rays ? 8 : 0) + 4) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
+    // light sample positions and bundle masks in HBM: general variants (per record) and the AO directions of
+    // the primary hits; the flat pipeline's `lit` keeps the light samples in LDS
+    const size_t hbm_rays = p.flat ? A : rays;
+    const size_t ray_recs = p.flat ? 1 : recs;
+    const size_t per_entry = 16 + 4 + recs * (5 * 16 + 4) + ray_recs * (12 * hbm_rays + (hbm_rays ? 8 : 0)) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
+    // `lit`: records per round such that their sample positions, masks and counts fit its LDS budget
+    {
+        const size_t pairs = S ? S : 1;
+        size_t round = kLitLdsBytes / (12 * pairs + 12);
+        if (round > static_cast<size_t>(kBlock)) round = kBlock;
+        if (round < 1) round = 1;
+        p.lit_round = static_cast<int>(round);
+        p.lit_lds_bytes = static_cast<int>(round * (12 * pairs + 12));
+        p.lit_lds_offset = static_cast<int>((scene_table_bytes(p) + 15) & ~static_cast<size_t>(15));
+    }
     const int owned = p.shard.owned_rows;
     auto row_count = [&](int j) -> size_t { return row_touched ? static_cast<size_t>(row_touched[j]) : static_cast<size_t>(p.shard.tiles_x); };
     // touched tiles of the fullest batch when the shard is cut into batches of R owned rows
@@ -1430,8 +1550,8 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     w.unit_hits = static_cast<size_t>(p.ws.unit_cap) * 4;
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
     w.queue_each = rec_cap * 16;
-    w.targets = rec_cap * 12 * rays;
-    w.cand = rays ? rec_cap * 8 : 0;
+    w.targets = (p.flat ? cap : rec_cap) * 12 * hbm_rays;
+    w.cand = hbm_rays ? (p.flat ? cap : rec_cap) * 8 : 0;
     w.lit0 = (p.flat ? rec_cap : cap) * 4;
     w.lit1 = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
@@ -1447,6 +1567,7 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
     const int levels = c.max_bounces < 0 ? 0 : c.max_bounces + 1;
     if (levels < 1) return;
     constexpr bool posed = kView != kViewLdsUnposed;
+    (void)soft;
     if (!p.flat) {  // general variants: one launch set per level; `level_shade` emits the light samples of the entries it appends
         const int grid = 256;
         for (int L = 0; L < levels; ++L) {
@@ -1465,8 +1586,7 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         hipLaunchKernelGGL(bounce_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
         hipLaunchKernelGGL(chase_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    if (soft) hipLaunchKernelGGL((light_samples_kernel<false, posed>), dim3(grid), dim3(kBlock), 0, stream, p.scene, p, 0);
-    hipLaunchKernelGGL(shadow_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p, 0);
+    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);
     if (c.ao_enabled && c.ao_samples > 0) {
         hipLaunchKernelGGL(ao_dirs_kernel<posed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
@@ -1484,11 +1604,10 @@ hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
 hipError_t launch_render(const RenderParams& p, hipStream_t stream, const LaunchMarks* marks) {
     const int n = owned_tiles(p);
     if (n <= 0) return hipSuccess;
-    const size_t dyn = p.scene_in_lds ? static_cast<size_t>(p.lds_face_entries) * 16 + static_cast<size_t>(p.lds_face_entries / 6) * kMeshTabWords * 4 +
-                                            static_cast<size_t>(p.lds_alpha_words) * 4
-                                      : 0;
+    const size_t dyn = scene_table_bytes(p);
     float4* out = reinterpret_cast<float4*>(p.out);
     uchar4* out8 = reinterpret_cast<uchar4*>(p.out8);
+    if (static_cast<size_t>(p.lit_lds_offset) != ((dyn + 15) & ~static_cast<size_t>(15))) return hipErrorInvalidValue;  // set by plan_workspace's caller
     for (int r0 = 0; r0 < p.shard.owned_rows; r0 += p.rows_per_batch) {
         const int rows = p.rows_per_batch < p.shard.owned_rows - r0 ? p.rows_per_batch : p.shard.owned_rows - r0;
         const int tile_base = r0 * p.shard.tiles_x;
