@@ -21,15 +21,16 @@
 //   chase           1 lane / level-1 record        the rest of the chain: reflect, closest hit, append, until the ray
 //                                     misses or maxBounces is reached (~10 % go on per level)
 //   ... then ONCE over the records of ALL levels (550 k + 55 k + 5 k + ... at 1080p / 4 spp):
-//   light_samples   1 lane / record   register-only truncated mt19937 → 2·S draws → the S disk sample
-//                                     positions, and the hit's bundle mask (meshes its shadow rays can meet)
-//   shadow          1 lane / (record, light sample)   exact any-hit test on the bundle mask → lit count
 //   ao_dirs, ao     (AO on, primary hits)  hemisphere directions + ball mask per hit; any hit within the radius
-//   shade           1 lane / record   Blinn-Phong (+AO) → the chain's stack of level colours
+//   lit             three phases per block of 256 records, handed over through LDS:
+//                   1 lane / record   register-only truncated mt19937 → 2·S draws → the S disk sample
+//                                     positions, and the hit's bundle mask (meshes its shadow rays can meet)
+//                   1 lane / (record, light sample)   exact any-hit test on the bundle mask → lit count
+//                   1 lane / record   Blinn-Phong (+AO) → the chain's stack of level colours
 //   resolve         1 lane / pixel    folds each sample's chain back to front, ordered sum of the pixel's sample
 //                                     colours (float addition order is part of the result), coalesced float4 / RGBA8 store
 //   (general variants — per-hit RNG streams longer than 227 draws, or more than kFlatMaxBounces bounces — run
-//   light_samples / shadow / level_shade once per recursion level instead of bounce .. shade)
+//   light_samples / shadow / level_shade once per recursion level instead of bounce .. lit)
 // Records live in HBM as SoA float4 arrays.  Every unit owns a fixed slot range (its samples); its
 // primary hits are compacted to the front of that range with an LDS prefix sum and a per-unit count —
 // NO global atomics on the hot path (a returning atomic on one word sustains only ~88 ops/us on this
@@ -928,15 +929,18 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------
-// lit (flat pipeline): light samples AND shadow rays of every record in one launch, handed over through
-// LDS.  Per block of up to `lit_round` records:
+// lit (flat pipeline): light samples, shadow rays AND shading of every record in one launch, handed over
+// through LDS.  Per block of up to `lit_round` records:
 //   phase A  a lane per record — the 397-step mt19937 seeding recurrence, the 2·S draws, the S disk
 //            sample positions and the record's bundle mask (shading.cpp:28-53) — into LDS;
 //   phase B  a lane per (record, light sample) — the exact any-hit test on the bundle mask — lit
-//            count by ballot (S a power of two) or LDS atomics.
-// As two kernels the positions and masks went through HBM (96 + 8 B written and read back per
+//            count by ballot (S a power of two) or LDS atomics, into LDS;
+//   phase C  a lane per record — Blinn-Phong with that visibility term (shading.cpp:62-96), times the AO
+//            factor for primary hits (raytracer.cpp:121-130; the AO stage runs before this kernel) — onto
+//            the chain's stack at the record's depth.
+// As separate kernels the positions and masks went through HBM (96 + 8 B written and read back per
 // record: ~180 MB of the metric frame's counted traffic), and the VALU-bound seeding chains could not
-// overlap the latency-bound shadow rays.  Hard shadows / a point light: phase B alone, one ray per record.
+// overlap the latency-bound shadow rays.  Hard shadows / a point light: no phase A, one ray per record.
 // ---------------------------------------------------------------------------------------------
 #ifndef MCRT_LIT_WAVES
 #define MCRT_LIT_WAVES 4
@@ -958,17 +962,18 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_dyn + p.lit_lds_offset);  // 16-aligned
     float* s_pos = reinterpret_cast<float*>(s_cand + round);
     uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + static_cast<size_t>(round) * pairs_per_hit * 3);
-    uint32_t* lit = ws.lit[0];
     const V3 lpos = ld3(scg.hdr->light_pos);
     const float lradius = scg.hdr->light_radius;
     const uint32_t lane = threadIdx.x & 63u;
+    const mcrt_config& cfg = p.cfg;
+    const int stride = ws.stack_stride;
     for_each_entry_block(ws, scope, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         for (uint32_t r0 = 0; r0 < n; r0 += round) {  // uniform
             const uint32_t m = min(round, n - r0);
             const uint32_t base = first + r0;
             // ---- phase A: a lane per record
             if (threadIdx.x < m) {
-                if (!pow2) s_lit[threadIdx.x] = 0u;
+                if (!pow2) s_lit[threadIdx.x] = 0u;  // (this thread's own read of it in phase C came first)
                 if (mode == SHADOW_SOFT) {
                     const uint32_t e = base + threadIdx.x;
                     const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
@@ -1011,16 +1016,28 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                     const unsigned long long bal = __ballot(visible);
                     if (q < total && (lane & (pairs_per_hit - 1u)) == 0u) {
                         const unsigned long long grp = (pairs_per_hit == 64u) ? bal : ((bal >> lane) & ((1ull << pairs_per_hit) - 1ull));
-                        lit[base + k] = static_cast<uint32_t>(__popcll(grp));
+                        s_lit[k] = static_cast<uint32_t>(__popcll(grp));
                     }
                 } else if (visible) {
                     atomicAdd(&s_lit[k], 1u);
                 }
             }
-            __syncthreads();  // the next round overwrites the positions
-            if (!pow2) {
-                if (threadIdx.x < m) lit[base + threadIdx.x] = s_lit[threadIdx.x];
-                __syncthreads();
+            __syncthreads();  // the counts are complete; the next round may overwrite the positions
+            // ---- phase C: a lane per record
+            if (threadIdx.x < m) {
+                const uint32_t e = base + threadIdx.x;
+                const Record r = load_record(ws, 0, e, true);
+                const uint32_t lit = s_lit[threadIdx.x];
+                const float vis = (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
+                C4 c = shade(scg, r.hit, normalize(r.ray.o - r.hit.p), vis);
+                if (cfg.ao_enabled && r.depth == 0) {  // occluded count from the ao stage (e < cap: a primary hit)
+                    const float ao = 1.0f - static_cast<float>(ws.lit[1][e]) / static_cast<float>(cfg.ao_samples);
+                    const float kk = 1.0f - cfg.ao_intensity * (1.0f - ao);
+                    c.r *= kk;
+                    c.g *= kk;
+                    c.b *= kk;
+                }
+                ws.stack[static_cast<size_t>(r.root) * stride + r.depth] = make_float4(c.r, c.g, c.b, c.a);
             }
         }
     });
@@ -1106,34 +1123,6 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uin
                 atomicAdd(&occ_out[e], 1u);
             }
         }
-    });
-}
-
-// shade (flat pipeline): the colour of every record — Blinn-Phong with its visibility term (shading.cpp:62-96),
-// times the AO factor for primary hits (raytracer.cpp:121-130) — onto its chain's stack at the record's depth.
-// Needs no scene tables: no ray is traced here.
-__global__ __launch_bounds__(kBlock) void shade_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
-    const SceneView sc = view_of(scene_blob);
-    const WaveSpace& ws = p.ws;
-    const mcrt_config& cfg = p.cfg;
-    const int mode = shadow_mode(sc, cfg);
-    const int S = cfg.shadow_samples;
-    const int stride = ws.stack_stride;
-    for_each_entry_block(ws, Scope{0, 1}, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
-        if (threadIdx.x >= n) return;
-        const uint32_t e = first + threadIdx.x;
-        const Record r = load_record(ws, 0, e, true);
-        const uint32_t lit = ws.lit[0][e];
-        const float vis = (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
-        C4 c = shade(sc, r.hit, normalize(r.ray.o - r.hit.p), vis);
-        if (cfg.ao_enabled && r.depth == 0) {  // raytracer.cpp:121-130; occluded count from the ao stage (e < cap: a primary hit)
-            const float ao = 1.0f - static_cast<float>(ws.lit[1][e]) / static_cast<float>(cfg.ao_samples);
-            const float k = 1.0f - cfg.ao_intensity * (1.0f - ao);
-            c.r *= k;
-            c.g *= k;
-            c.b *= k;
-        }
-        ws.stack[static_cast<size_t>(r.root) * stride + r.depth] = make_float4(c.r, c.g, c.b, c.a);
     });
 }
 
@@ -1438,7 +1427,10 @@ static bool soft_sampling(const mcrt_config& c) { return c.soft_shadows && c.sha
 // The flat pipeline keeps the records of every level at once: its arrays are laid out for up to
 // kFlatMaxBounces reflection levels (1 + maxBounces records per sample slot in the worst case).
 constexpr int kFlatMaxBounces = 8;
-constexpr size_t kLitLdsBytes = 32 * 1024;  // `lit`: LDS for the sample positions, masks and counts of a round of records
+#ifndef MCRT_LIT_LDS_KB
+#define MCRT_LIT_LDS_KB 32
+#endif
+constexpr size_t kLitLdsBytes = MCRT_LIT_LDS_KB * 1024;  // `lit`: LDS for the sample positions, masks and counts of a round of records
 // rare features that need the general kernel variants (one launch set per level, ping-pong queues): per-hit RNG
 // streams longer than the register-only engine covers (they run AO inside `level_shade`, sequentially), or
 // more bounces than the flat record arrays are laid out for
@@ -1481,7 +1473,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     // the primary hits; the flat pipeline's `lit` keeps the light samples in LDS
     const size_t hbm_rays = p.flat ? A : rays;
     const size_t ray_recs = p.flat ? 1 : recs;
-    const size_t per_entry = 16 + 4 + recs * (5 * 16 + 4) + ray_recs * (12 * hbm_rays + (hbm_rays ? 8 : 0)) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
+    const size_t per_entry = 16 + 4 + recs * 5 * 16 + ray_recs * (12 * hbm_rays + (hbm_rays ? 8 : 0) + 4) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
     // `lit`: records per round such that their sample positions, masks and counts fit its LDS budget
     {
         const size_t pairs = S ? S : 1;
@@ -1552,7 +1544,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     w.queue_each = rec_cap * 16;
     w.targets = (p.flat ? cap : rec_cap) * 12 * hbm_rays;
     w.cand = hbm_rays ? (p.flat ? cap : rec_cap) * 8 : 0;
-    w.lit0 = (p.flat ? rec_cap : cap) * 4;
+    w.lit0 = p.flat ? 4 : cap * 4;  // the flat pipeline keeps the lit counts in LDS
     w.lit1 = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
     w.counters = static_cast<size_t>(kCounterWords) * 4;
@@ -1586,12 +1578,11 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         hipLaunchKernelGGL(bounce_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
         hipLaunchKernelGGL(chase_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);
-    if (c.ao_enabled && c.ao_samples > 0) {
+    if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
         hipLaunchKernelGGL(ao_dirs_kernel<posed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
+    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);
 }
 
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
