@@ -105,7 +105,7 @@ struct Lane {
     hipStream_t stream = nullptr;  // owned; unused for lane 0
     hipEvent_t done = nullptr;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
-    DeviceBuffer tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queues[5], targets, cand, lit[2], stack, counters, hit_rng;
+    DeviceBuffer tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queues[5], texel_refs, targets, cand, lit[2], stack, counters, hit_rng;
     RngKey rng_key;               // which tile seeds tile_rng holds (ptr == nullptr: none)
 };
 
@@ -282,6 +282,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         want(s->tile_mask, w.tile_mask);
         want(s->unit_hits, w.unit_hits);
         for (auto& q : s->queues) want(q, w.queue_each);
+        want(s->texel_refs, w.texel_refs);
         want(s->targets, w.targets);
         want(s->cand, w.cand);
         want(s->lit[0], w.lit0);
@@ -302,6 +303,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         s->tile_rng.release(), s->tile_draws.release(), s->scol.release(), s->end.release(), s->units.release(), s->tile_mask.release();
         s->unit_hits.release();
         for (auto& q : s->queues) q.release();
+        s->texel_refs.release();
         s->targets.release(), s->cand.release(), s->lit[0].release(), s->lit[1].release(), s->stack.release();
         s->counters.release(), s->hit_rng.release();
         sc->budget /= 2;
@@ -321,6 +323,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         ws.q_n[k] = static_cast<float4*>(s->queues[3].ptr) + static_cast<size_t>(k) * ws.cap;
         ws.q_t[k] = static_cast<float4*>(s->queues[4].ptr) + static_cast<size_t>(k) * ws.cap;
     }
+    ws.q_x = static_cast<int32_t*>(s->texel_refs.ptr);
     ws.targets = static_cast<float*>(s->targets.ptr);
     ws.cand = static_cast<unsigned long long*>(s->cand.ptr);
     ws.lit[0] = static_cast<uint32_t*>(s->lit[0].ptr);
@@ -562,6 +565,7 @@ size_t workspace_bytes(const mcrt_scene* s) {
     for (const Lane& ln : s->lanes) {
         n += ln.tile_rng.bytes + ln.tile_draws.bytes + ln.scol.bytes + ln.end.bytes + ln.units.bytes + ln.unit_hits.bytes + ln.tile_mask.bytes;
         for (const auto& q : ln.queues) n += q.bytes;
+        n += ln.texel_refs.bytes;
         n += ln.targets.bytes + ln.cand.bytes + ln.lit[0].bytes + ln.lit[1].bytes + ln.stack.bytes + ln.counters.bytes + ln.hit_rng.bytes;
     }
     return n;

@@ -38,14 +38,23 @@ struct WaveSpace {
     uint32_t unit_cap;      // capacity of `units`
     uint32_t tile_cap;      // tiles of a batch that may be touched by meshes (host-side superset of the device's culling):
                             // touched tile number k of a batch owns slots [k, k+1) * tile_slots
-    // Hit records, SoA.  q_x[1] = q_x[0] + cap.  Flat pipeline: q_x[0] is ONE array of rec_cap records — the
-    // primary hits at their slot index (< cap), the records of every deeper level densely from index cap on.
-    // General variants: q_x[level & 1], ping-pong by level.
-    float4* q_o[2];         // ray origin  (.w = root = the chain's sample slot, bit-cast)
-    float4* q_d[2];         // ray direction (.w = depth, bit-cast)
-    float4* q_p[2];         // hit point
-    float4* q_n[2];         // hit normal (as intersectMesh returns it)
-    float4* q_t[2];         // texel colour
+    // Hit records, SoA.  q_*[1] = q_*[0] + cap.
+    // General variants: q_*[level & 1], ping-pong by level, every field written:
+    //   q_o ray origin (.w = root = the chain's sample slot, bit-cast), q_d ray direction (.w = depth),
+    //   q_p hit point, q_n hit normal (as intersectMesh returns it), q_t texel colour.
+    // Flat pipeline: q_*[0] is ONE array of rec_cap records — the primary hits at their slot index (< cap), the
+    // records of every deeper level densely from index cap on — in a compact form (36 B instead of 80 for an
+    // un-posed scene seen through a pinhole):
+    //   q_p hit point (.w = root), q_d ray direction (.w = depth | face axis << 8 | min-side << 10 | exit-face << 11),
+    //   q_x texel reference of the face (the colour is fetched from the pool where the record is shaded),
+    //   q_n only when the scene holds posed meshes (else the normal follows from the face code),
+    //   q_o only for records below the primary hits, and for those too under depth of field (else the camera position)
+    float4* q_o[2];
+    float4* q_d[2];
+    float4* q_p[2];
+    float4* q_n[2];
+    float4* q_t[2];
+    int32_t* q_x;           // [rec_cap] flat pipeline: texel reference per record
     float* targets;         // [rec_cap][3*shadowSamples] light sample positions per record (level 0: reused for the AO directions)
     unsigned long long* cand;  // [rec_cap] per record: meshes its soft-shadow rays can meet (conservative first pass, once per hit)
     uint32_t* lit[2];       // [0]: [rec_cap] visible light samples per record; [1]: [cap] occluded AO samples of the primary
@@ -90,7 +99,7 @@ Shard make_shard(const mcrt_config& cfg, int first, int step);
 // p.ws.cap / p.ws.stack_stride.  budget_bytes bounds the per-batch workspace (a batch is never
 // smaller than one tile row).
 struct WorkspaceBytes {
-    size_t tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queue_each, targets, cand, lit0, lit1, stack, counters, hit_rng;
+    size_t tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queue_each, texel_refs, targets, cand, lit0, lit1, stack, counters, hit_rng;
 };
 // row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
 WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);

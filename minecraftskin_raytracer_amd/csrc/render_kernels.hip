@@ -344,6 +344,57 @@ __device__ __forceinline__ void push_entry(const WaveSpace& ws, int parity, uint
     ws.q_t[parity][e] = make_float4(hit.tex.r, hit.tex.g, hit.tex.b, hit.tex.a);
 }
 
+// ---- compact hit records of the flat pipeline (kernels.h: WaveSpace::q_*) -------------------------------
+// .w of q_d: depth | face axis << 8 | min-side << 10 | exit-face << 11
+__device__ __forceinline__ uint32_t record_code(int depth, const Hit& h) {
+    return static_cast<uint32_t>(depth) | (static_cast<uint32_t>(h.axis) << 8) | (h.neg ? 1u << 10 : 0u) | (h.back ? 1u << 11 : 0u);
+}
+// with_origin: records below the primary hits, and primary hits under depth of field (otherwise the ray
+// starts at the camera position)
+__device__ __forceinline__ void push_record(const WaveSpace& ws, bool posed, uint32_t e, const Ray& ray, const Hit& hit, uint32_t root, int depth,
+                                            bool with_origin) {
+    ws.q_p[0][e] = make_float4(hit.p.x, hit.p.y, hit.p.z, __uint_as_float(root));
+    ws.q_d[0][e] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(record_code(depth, hit)));
+    ws.q_x[e] = hit.texel;
+    if (posed) ws.q_n[0][e] = make_float4(hit.n.x, hit.n.y, hit.n.z, 0.0f);
+    if (with_origin) ws.q_o[0][e] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+}
+// what the chain and shadow stages read of a record: hit point, normal (as intersectMesh returned it),
+// ray direction, depth, root
+struct RecordGeom {
+    V3 p, n, d;
+    uint32_t root;
+    int depth;
+};
+__device__ __forceinline__ RecordGeom load_geom(const WaveSpace& ws, bool posed, uint32_t e) {
+    const float4 qp = ws.q_p[0][e], qd = ws.q_d[0][e];
+    const uint32_t code = __float_as_uint(qd.w);
+    RecordGeom g;
+    g.p = mk(qp.x, qp.y, qp.z);
+    g.d = mk(qd.x, qd.y, qd.z);
+    g.root = __float_as_uint(qp.w);
+    g.depth = static_cast<int>(code & 0xffu);
+    if (posed) {
+        const float4 qn = ws.q_n[0][e];
+        g.n = mk(qn.x, qn.y, qn.z);
+    } else {
+        g.n = unposed_normal(static_cast<int>((code >> 8) & 3u), ((code >> 10) & 1u) != 0u, ((code >> 11) & 1u) != 0u);
+    }
+    return g;
+}
+// only point and normal (a shadow or AO ray lane)
+__device__ __forceinline__ void load_point_normal(const WaveSpace& ws, bool posed, uint32_t e, V3& P, V3& N) {
+    const float4 qp = ws.q_p[0][e];
+    P = mk(qp.x, qp.y, qp.z);
+    if (posed) {
+        const float4 qn = ws.q_n[0][e];
+        N = mk(qn.x, qn.y, qn.z);
+    } else {
+        const uint32_t code = __float_as_uint(ws.q_d[0][e].w);
+        N = unposed_normal(static_cast<int>((code >> 8) & 3u), ((code >> 10) & 1u) != 0u, ((code >> 11) & 1u) != 0u);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // plan_tiles: one wave per tile of the batch — which meshes can touch the tile, its units and slot
 // range (plan_tile), then the tile's draws (tile_stream_wave)
@@ -529,7 +580,11 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
             const int rank = block_rank(is_hit, s_wcnt, total);
             if (is_hit) {
                 const uint32_t e = slot_base + unit_hits + static_cast<uint32_t>(rank);
-                push_entry(ws, 0, e, ray, hit, sample_slot, 0);  // root of the chain = its sample's colour slot
+                // root of the chain = its sample's colour slot
+                if (p.flat)
+                    push_record(ws, p.scene_posed != 0, e, ray, hit, sample_slot, 0, dof);
+                else
+                    push_entry(ws, 0, e, ray, hit, sample_slot, 0);
             }
             unit_hits += static_cast<uint32_t>(total);
         }
@@ -678,6 +733,7 @@ __global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void bounce_kernel(const
     if (blockIdx.x >= ws.counters[kCntUnits]) return;  // before the collective staging
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const int max_b = p.cfg.max_bounces;
+    const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
     for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         bool next_hit = false;
         Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
@@ -685,12 +741,12 @@ __global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void bounce_kernel(const
         nhit.hit = false;
         uint32_t root = 0;
         if (threadIdx.x < n) {
-            const Record r = load_record(ws, 0, first + threadIdx.x, false);
+            const RecordGeom r = load_geom(ws, posed, first + threadIdx.x);
             root = r.root;
             if (max_b < 1) {
                 ws.end[root] = chain_code(1, true);
             } else {
-                nray = reflect_ray(r.ray, r.hit);
+                nray = reflect_ray(r.d, r.p, r.n);
                 nhit = hit_scene(sc, nray, ~0ull);
                 if (nhit.hit)
                     next_hit = true;
@@ -703,7 +759,7 @@ __global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void bounce_kernel(const
         if (total > 0) {  // uniform
             if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep1], static_cast<uint32_t>(total));
             __syncthreads();
-            if (next_hit) push_entry(ws, 0, ws.cap + s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, 1);
+            if (next_hit) push_record(ws, posed, ws.cap + s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, 1, true);
             __syncthreads();
         }
     });
@@ -725,16 +781,17 @@ __global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void chase_kernel(const 
     if (static_cast<unsigned long long>(blockIdx.x) * kBlock >= count1) return;  // before the collective staging
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const int max_b = p.cfg.max_bounces;
+    const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
     const uint32_t deep2_base = ws.cap + count1;  // records of levels >= 2 go behind the level-1 records
     for_each_dense_block(ws.cap, count1, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         bool active = threadIdx.x < n;
-        Record r;
+        RecordGeom r;
         r.root = 0;
         r.depth = 1;
-        r.ray = Ray{mk(0, 0, 0), mk(0, 0, 0)};
-        r.hit.p = mk(0, 0, 0);
-        r.hit.n = mk(0, 0, 0);
-        if (active) r = load_record(ws, 0, first + threadIdx.x, false);
+        r.d = mk(0, 0, 0);
+        r.p = mk(0, 0, 0);
+        r.n = mk(0, 0, 0);
+        if (active) r = load_geom(ws, posed, first + threadIdx.x);
         for (;;) {
             bool next_hit = false;
             Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
@@ -745,7 +802,7 @@ __global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void chase_kernel(const 
                     ws.end[r.root] = chain_code(r.depth + 1, true);
                     active = false;
                 } else {
-                    nray = reflect_ray(r.ray, r.hit);
+                    nray = reflect_ray(r.d, r.p, r.n);
                     nhit = hit_scene(sc, nray, ~0ull);
                     if (nhit.hit) {
                         next_hit = true;
@@ -761,10 +818,10 @@ __global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void chase_kernel(const 
             if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep2], static_cast<uint32_t>(total));
             __syncthreads();
             if (next_hit) {
-                push_entry(ws, 0, deep2_base + s_out_base + static_cast<uint32_t>(rank), nray, nhit, r.root, r.depth + 1);
-                r.ray = nray;
-                r.hit.p = nhit.p;
-                r.hit.n = nhit.n;
+                push_record(ws, posed, deep2_base + s_out_base + static_cast<uint32_t>(rank), nray, nhit, r.root, r.depth + 1, true);
+                r.d = nray.d;
+                r.p = nhit.p;
+                r.n = nhit.n;
                 ++r.depth;
             }
             __syncthreads();
@@ -967,6 +1024,9 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const uint32_t lane = threadIdx.x & 63u;
     const mcrt_config& cfg = p.cfg;
     const int stride = ws.stack_stride;
+    const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
+    const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
+    const V3 cam_pos = ld3(scg.hdr->cam_pos);
     for_each_entry_block(ws, scope, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         for (uint32_t r0 = 0; r0 < n; r0 += round) {  // uniform
             const uint32_t m = min(round, n - r0);
@@ -975,11 +1035,10 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
             if (threadIdx.x < m) {
                 if (!pow2) s_lit[threadIdx.x] = 0u;  // (this thread's own read of it in phase C came first)
                 if (mode == SHADOW_SOFT) {
-                    const uint32_t e = base + threadIdx.x;
-                    const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
-                    const V3 P = mk(hp.x, hp.y, hp.z), N = mk(hn.x, hn.y, hn.z);
+                    const RecordGeom g = load_geom(ws, posed, base + threadIdx.x);
+                    const V3 P = g.p, N = g.n;
                     MtShort rng;
-                    rng.seed(shadow_seed(P, __float_as_int(ws.q_d[0][e].w)));
+                    rng.seed(shadow_seed(P, g.depth));
                     s_cand[threadIdx.x] = bundle_candidates<kPosed>(scg, P + N * 1e-3f, lpos, lradius);
                     const LightFrame frame = light_frame(scg, P);
                     float* dst = s_pos + static_cast<size_t>(threadIdx.x) * 3 * S;
@@ -1002,10 +1061,8 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                 uint32_t k = 0;
                 if (q < total) {
                     k = q / pairs_per_hit;
-                    const uint32_t e = base + k;
-                    const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
-                    const V3 P = mk(hp.x, hp.y, hp.z);
-                    V3 N = mk(hn.x, hn.y, hn.z);
+                    V3 P, N;
+                    load_point_normal(ws, posed, base + k, P, N);
                     if (mode == SHADOW_HARD) N = normalize(N);
                     if (mode == SHADOW_SOFT)
                         visible = !in_shadow_masked(sc, P, N, ld3(s_pos + static_cast<size_t>(q) * 3), s_cand[k]);
@@ -1026,10 +1083,20 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
             // ---- phase C: a lane per record
             if (threadIdx.x < m) {
                 const uint32_t e = base + threadIdx.x;
-                const Record r = load_record(ws, 0, e, true);
+                const RecordGeom r = load_geom(ws, posed, e);
+                Hit hit;
+                hit.hit = true;
+                hit.p = r.p;
+                hit.n = r.n;
+                hit.tex = texel_color(scg, ws.q_x[e]);  // the colour of the face's texel, from the pool
+                V3 origin = cam_pos;
+                if (r.depth > 0 || dof) {
+                    const float4 qo = ws.q_o[0][e];
+                    origin = mk(qo.x, qo.y, qo.z);
+                }
                 const uint32_t lit = s_lit[threadIdx.x];
                 const float vis = (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
-                C4 c = shade(scg, r.hit, normalize(r.ray.o - r.hit.p), vis);
+                C4 c = shade(scg, hit, normalize(origin - hit.p), vis);
                 if (cfg.ao_enabled && r.depth == 0) {  // occluded count from the ao stage (e < cap: a primary hit)
                     const float ao = 1.0f - static_cast<float>(ws.lit[1][e]) / static_cast<float>(cfg.ao_samples);
                     const float kk = 1.0f - cfg.ao_intensity * (1.0f - ao);
@@ -1055,9 +1122,9 @@ __global__ __launch_bounds__(kBlock) void ao_dirs_kernel(const uint8_t* __restri
     for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
         if (threadIdx.x >= n) return;
         const uint32_t e = first + threadIdx.x;
-        const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
-        const V3 P = mk(hp.x, hp.y, hp.z);
-        const V3 N = normalize(mk(hn.x, hn.y, hn.z));
+        V3 P, Nraw;
+        load_point_normal(ws, p.scene_posed != 0, e, P, Nraw);
+        const V3 N = normalize(Nraw);
         const V3 T = (__builtin_fabsf(N.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), N)) : normalize(cross(mk(0, 1, 0), N));
         const V3 B = cross(N, T);
         // the meshes any of this hit's AO rays can meet (the primary hits' shadow masks are consumed by now)
@@ -1107,10 +1174,11 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uin
                 const uint32_t k = q / A;
                 const uint32_t j = q - k * A;
                 e = first + k;
-                const float4 hp = ws.q_p[0][e], hn = ws.q_n[0][e];
-                const V3 N = normalize(mk(hn.x, hn.y, hn.z));
+                V3 P, Nraw;
+                load_point_normal(ws, p.scene_posed != 0, e, P, Nraw);
+                const V3 N = normalize(Nraw);
                 const V3 dir = ld3(ws.targets + (static_cast<size_t>(e) * A + j) * 3);
-                const Ray r{mk(hp.x, hp.y, hp.z) + N * 1e-3f, dir};
+                const Ray r{P + N * 1e-3f, dir};
                 occluded = any_hit_masked(sc, r, radius, ws.cand[e]);
             }
             if (pow2) {
@@ -1473,7 +1541,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     // the primary hits; the flat pipeline's `lit` keeps the light samples in LDS
     const size_t hbm_rays = p.flat ? A : rays;
     const size_t ray_recs = p.flat ? 1 : recs;
-    const size_t per_entry = 16 + 4 + recs * 5 * 16 + ray_recs * (12 * hbm_rays + (hbm_rays ? 8 : 0) + 4) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
+    const size_t per_entry = 16 + 4 + recs * (5 * 16 + 4) + ray_recs * (12 * hbm_rays + (hbm_rays ? 8 : 0) + 4) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
     // `lit`: records per round such that their sample positions, masks and counts fit its LDS budget
     {
         const size_t pairs = S ? S : 1;
@@ -1542,6 +1610,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     w.unit_hits = static_cast<size_t>(p.ws.unit_cap) * 4;
     w.tile_mask = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 8;
     w.queue_each = rec_cap * 16;
+    w.texel_refs = p.flat ? rec_cap * 4 : 4;
     w.targets = (p.flat ? cap : rec_cap) * 12 * hbm_rays;
     w.cand = hbm_rays ? (p.flat ? cap : rec_cap) * 8 : 0;
     w.lit0 = p.flat ? 4 : cap * 4;  // the flat pipeline keeps the lit counts in LDS

@@ -93,6 +93,12 @@ struct Hit {
     float t;
     V3 p, n;
     C4 tex;
+    // how the hit was found, for compact hit records: the texel reference of the face (pool index or
+    // MCRT_TEX_NULL / MCRT_TEX_EMPTY) and the face in the mesh's local frame — for an un-posed mesh the normal
+    // is face_normal(axis, neg), negated when `back` (the outer layer's exit face, intersection.cpp:349-357)
+    int texel;
+    int axis;
+    bool neg, back;
 };
 
 // Views of the flat blob.  SceneView reads everything from HBM (probes, rare sequential paths).
@@ -322,6 +328,13 @@ DEV int face_slot(int axis, bool neg) {
 DEV V3 face_normal(int axis, bool neg) {
     float s = neg ? -1.0f : 1.0f;
     return mk(axis == 0 ? s : 0.0f, axis == 1 ? s : 0.0f, axis == 2 ? s : 0.0f);
+}
+
+// the hit normal intersectMesh returns for an un-posed mesh (:297-303 and, for the exit face, :354)
+DEV V3 unposed_normal(int axis, bool neg, bool back) {
+    V3 n = face_normal(axis, neg);
+    if (back) n = n * -1.0f;
+    return n;
 }
 
 // computeFaceUV :136-196
@@ -649,6 +662,10 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
     h.p = best.p;
     h.n = mk(0, 0, 0);
     h.tex = C4{0.0f, 0.0f, 0.0f, 1.0f};
+    h.texel = best.texel;
+    h.axis = best.axis;
+    h.neg = best.neg;
+    h.back = best.back;
     if (h.hit) {
         const MeshData m = mesh_lane(sc, best_mesh);
         V3 n = face_normal(best.axis, best.neg);
@@ -993,13 +1010,14 @@ DEV float hit_visibility(const SV& sc, const mcrt_config& cfg, const Hit& hit, i
     return in_shadow(sc, hit.p, normalize(hit.n), lpos) ? 0.0f : 1.0f;
 }
 
-// reflection ray of a hit (:133-139)
-DEV Ray reflect_ray(const Ray& ray, const Hit& hit) {
-    V3 N = normalize(hit.n);
-    V3 D = normalize(ray.d);
+// reflection ray of a hit (:133-139): from the incoming direction, the hit point and its normal
+DEV Ray reflect_ray(V3 dir, V3 point, V3 normal) {
+    V3 N = normalize(normal);
+    V3 D = normalize(dir);
     V3 R = normalize(D - N * (2.0f * dot(D, N)));
-    return Ray{hit.p + N * 1e-3f, R};
+    return Ray{point + N * 1e-3f, R};
 }
+DEV Ray reflect_ray(const Ray& ray, const Hit& hit) { return reflect_ray(ray.d, hit.p, hit.n); }
 
 // One fold step of the recursion unwinding (:143-147): level colour `c` (alpha = texel alpha)
 // combined with the colour returned by the deeper level.
