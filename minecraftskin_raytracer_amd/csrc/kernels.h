@@ -59,7 +59,8 @@ struct WaveSpace {
     unsigned long long* cand;  // [rec_cap] per record: meshes its soft-shadow rays can meet (conservative first pass, once per hit)
     uint32_t* lit[2];       // [0]: [rec_cap] visible light samples per record; [1]: [cap] occluded AO samples of the primary
                             // hits (general variants: ping-pong by level parity, [cap] each)
-    float4* stack;          // [cap][stack_stride] level colours of the chain of sample slot r, by depth
+    float4* stack;          // [stack_stride][cap] level colours of the chains, plane-major: depth d of the chain of sample slot r
+                            // at [d * cap + r] — the level-0 colours of neighbouring samples share cache lines
     uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [2] records of levels >= 2, [8 + L] entries of level L >= 1
                             // ([9] = level-1 records), [last] touched-tile bound exceeded (never, by construction; sticky);
                             // cleared per pass but for the last

@@ -1023,7 +1023,6 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const float lradius = scg.hdr->light_radius;
     const uint32_t lane = threadIdx.x & 63u;
     const mcrt_config& cfg = p.cfg;
-    const int stride = ws.stack_stride;
     const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
     const V3 cam_pos = ld3(scg.hdr->cam_pos);
@@ -1104,7 +1103,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                     c.g *= kk;
                     c.b *= kk;
                 }
-                ws.stack[static_cast<size_t>(r.root) * stride + r.depth] = make_float4(c.r, c.g, c.b, c.a);
+                ws.stack[static_cast<size_t>(r.depth) * ws.cap + r.root] = make_float4(c.r, c.g, c.b, c.a);  // plane-major: [depth][sample slot]
             }
         }
     });
@@ -1214,7 +1213,6 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
     const int par = level & 1;
     const int mode = shadow_mode(sc, cfg);
     const int S = cfg.shadow_samples;
-    const int stride = ws.stack_stride;
     const float* fb = sc.hdr->background;
     const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
     uint32_t* my_rng = nullptr;
@@ -1244,7 +1242,7 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
                 nray = reflect_ray(r.ray, r.hit);
                 nhit = hit_scene(sc, nray, ~0ull);
                 if (nhit.hit) {  // the chain goes on: its level colour waits on the stack for the fold
-                    ws.stack[static_cast<size_t>(root) * stride + depth] = make_float4(c.r, c.g, c.b, c.a);
+                    ws.stack[static_cast<size_t>(depth) * ws.cap + root] = make_float4(c.r, c.g, c.b, c.a);
                     next_hit = true;
                 } else {  // bounced ray missed → flat background (raytracer.cpp:94-102), folded in at once (:143-147)
                     tail = fold_reflection(c, flat_bg);
@@ -1253,7 +1251,7 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
             }
             if (done) {  // unwind the recursion: fold the shallower levels' colours back to front
                 for (int d = depth - 1; d >= 0; --d) {
-                    const float4 sd = ws.stack[static_cast<size_t>(root) * stride + d];
+                    const float4 sd = ws.stack[static_cast<size_t>(d) * ws.cap + root];
                     tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
                 }
                 ws.scol[root] = make_float4(tail.r, tail.g, tail.b, tail.a);
@@ -1291,19 +1289,20 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
 // missed (:94-102), the clamped last level colour when it stopped at maxBounces (:146-147).
 // A thread per SAMPLE fetches / folds the colour; the pixel's samples meet in LDS and one thread per
 // pixel adds them in order (float addition order is part of the result).
-__device__ __forceinline__ float4 sample_colour(const WaveSpace& ws, uint32_t slot, int stride, const C4& flat_bg) {
+__device__ __forceinline__ float4 sample_colour(const WaveSpace& ws, uint32_t slot, const C4& flat_bg) {
     const uint32_t code = ws.end[slot];
     if (code == 0u) return ws.scol[slot];
-    const float4* lv = ws.stack + static_cast<size_t>(slot) * stride;
+    const float4* lv = ws.stack + slot;  // level d of the chain: lv[d * cap]
+    const size_t plane = ws.cap;
     C4 tail = flat_bg;
     int dd = static_cast<int>(code >> 1) - 1;  // the chain's last record
     if (code & 1u) {
-        const float4 last = lv[dd];
+        const float4 last = lv[dd * plane];
         tail = clamp4(C4{last.x, last.y, last.z, last.w});
         --dd;
     }
     for (; dd >= 0; --dd) {
-        const float4 sd = lv[dd];
+        const float4 sd = lv[dd * plane];
         tail = fold_reflection(C4{sd.x, sd.y, sd.z, sd.w}, tail);
     }
     return make_float4(tail.r, tail.g, tail.b, tail.a);
@@ -1316,7 +1315,6 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
     const uint32_t n_units = ws.counters[kCntUnits];
     const uint32_t spp = cfg.samples_per_pixel > 1 ? static_cast<uint32_t>(cfg.samples_per_pixel) : 1u;
     const float inv_spp = 1.0f / static_cast<float>(spp);
-    const int stride = ws.stack_stride;
     const float* fb = view_of(scene_blob).hdr->background;
     const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
     const uint32_t chunk_px = spp <= static_cast<uint32_t>(kBlock) ? static_cast<uint32_t>(kBlock) / spp : 0u;  // pixels per pass (0: a pixel per thread, serially)
@@ -1336,7 +1334,7 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
             for (uint32_t i = pp0 + threadIdx.x; i < pp1; i += kBlock) {
                 float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 for (uint32_t s = 0; s < spp; ++s) {
-                    const float4 c = sample_colour(ws, d.w + (i - pp0) * spp + s, stride, flat_bg);
+                    const float4 c = sample_colour(ws, d.w + (i - pp0) * spp + s, flat_bg);
                     acc.x += c.x, acc.y += c.y, acc.z += c.z, acc.w += c.w;
                 }
                 put_pixel(tg, i, acc);
@@ -1345,7 +1343,7 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
         }
         for (uint32_t p0 = pp0; p0 < pp1; p0 += chunk_px) {  // uniform
             const uint32_t npx = min(chunk_px, pp1 - p0);
-            if (threadIdx.x < npx * spp) s_col[threadIdx.x] = sample_colour(ws, d.w + (p0 - pp0) * spp + threadIdx.x, stride, flat_bg);
+            if (threadIdx.x < npx * spp) s_col[threadIdx.x] = sample_colour(ws, d.w + (p0 - pp0) * spp + threadIdx.x, flat_bg);
             __syncthreads();
             if (threadIdx.x < npx) {
                 float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
