@@ -152,6 +152,9 @@ def main() -> None:
     # produces a sequence of frames overlaps the chain of one frame with the dense kernels of the
     # next.  Every frame is rendered completely; `latency_ms` below is the one-frame-at-a-time figure.
     F = max(1, args.frames_in_flight)
+    # every handle plans its workspace against a budget of its own (default: a third of the HBM); F handles in
+    # flight share the device, so each gets a share (a frame that needs more is cut into more passes)
+    os.environ.setdefault("MCRT_WORKSPACE_MB", str(max(2048, 160 * 1024 // (F + 1))))
     scenes_ = [M.DeviceScene(sd, device=local_rank) for _ in range(F)]
     if F > 1:  # the frames in flight already fill the chip (and the hardware queues): one stream per frame
         for sc_ in scenes_:

@@ -173,7 +173,7 @@ void mcrt_scene_destroy(mcrt_scene* scene);
 int mcrt_render_device(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_first,
                        int tile_row_step, int out_layout, float* d_out_rgba, void* stream);
 
-/* mcrt_scene_destroy keeps the scene's device workspace (up to MCRT_POOL_MB, default 8192 MiB; one
+/* mcrt_scene_destroy keeps the scene's device workspace (up to MCRT_POOL_MB, default 49152 MiB; one
  * idle set per device) for the next mcrt_scene_create / one-shot render on that device, because
  * allocating it dominates a single small render.  mcrt_trim() frees what is being kept. */
 void mcrt_trim(void);

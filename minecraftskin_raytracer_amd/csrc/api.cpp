@@ -574,11 +574,13 @@ size_t workspace_bytes(const mcrt_scene* s) {
 std::mutex g_pool_mutex;
 std::vector<mcrt_scene*> g_pool;  // idle scene shells, at most one per device
 
-// keeps `s` for reuse unless it is large (MCRT_POOL_MB, default 8192) or the device already has one
+// keeps `s` for reuse unless it is large (MCRT_POOL_MB, default 49152 — a sixth of the MI355X's 288 GB: re-allocating
+// the tens of GB a 4K / 8K frame needs made each one-shot call of such a frame take about a second) or the
+// device already has one
 bool pool_scene(mcrt_scene* s) {
     static const size_t limit = [] {
         const char* e = std::getenv("MCRT_POOL_MB");
-        long long mb = e ? std::atoll(e) : 8192;
+        long long mb = e ? std::atoll(e) : 49152;
         return static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
     }();
     if (workspace_bytes(s) > limit) return false;

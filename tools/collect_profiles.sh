@@ -1,8 +1,9 @@
 #!/bin/bash
-# One GPU session that produces everything profiles/<tag>/ holds.   usage: tools/collect_profiles.sh <tag>
+# One GPU session that produces everything profiles/<tag>/ holds.   usage: tools/collect_profiles.sh <tag> [quick]
 # (run through gpurun; results land in gpurun_out/<tag>/ — copy what is to be judged into profiles/<tag>/)
 set -u
 TAG=${1:-prof}
+QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -16,10 +17,22 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bench -- python
 python3 $R/tools/trace_summary.py $O/trace_bench 40 > $O/kernel_timeline_bench.txt 2>&1
 # one lane: the plain dependency chain of a frame, kernel by kernel
 MCRT_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_1lane -- python3 $R/tools/gpu_case.py base 10 > $O/trace_1lane.log 2>&1
-python3 $R/tools/trace_summary.py $O/trace_1lane 16 > $O/kernel_timeline_1lane.txt 2>&1
+python3 $R/tools/trace_summary.py $O/trace_1lane 9 > $O/kernel_timeline_1lane.txt 2>&1
+# what the reference GUI renders by default (1080p, 64 spp, AO 16, depth of field): chain and bench line
+MCRT_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_gui -- python3 $R/tools/gpu_case.py gui 5 > $O/trace_gui.log 2>&1
+python3 $R/tools/trace_summary.py $O/trace_gui 12 > $O/kernel_timeline_gui_defaults.txt 2>&1
+cd $R
+: > $O/other_workloads.jsonl
+for W in gui_defaults 256_b1_spp1_S64 4k_b4_spp4_S64 4k_b8_spp16_S64 8k_b8_spp64_S32; do
+  timeout -k 10 400 python3 bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline --check >> $O/other_workloads.jsonl 2>> $O/bench.err || echo "bench $W failed"
+done
 # counters, one lane so that dispatches line up across passes
-MCRT_LANES=1 PMC_SETS=all $R/tools/pmc_run.sh gpurun_out/$TAG/pmc tools/gpu_case.py base 1 > $O/pmc_dispatches.txt 2>&1
+if [ -z "$QUICK" ]; then SETS=all; else SETS=core; fi
+MCRT_LANES=1 PMC_SETS=$SETS $R/tools/pmc_run.sh gpurun_out/$TAG/pmc tools/gpu_case.py base 1 > $O/pmc_dispatches.txt 2>&1
+python3 $R/tools/pmc_frame.py $O/pmc_dispatches.txt > $O/pmc_frame.txt 2>&1
 cp $O/trace_bench/*/*kernel_stats.csv $O/kernel_stats_bench.csv 2>/dev/null
 cp $O/trace_1lane/*/*kernel_stats.csv $O/kernel_stats_1lane.csv 2>/dev/null
+cp $O/trace_gui/*/*kernel_stats.csv $O/kernel_stats_gui_defaults.csv 2>/dev/null
 ls $O
+cat $O/pmc_frame.txt
 cat $O/bench.json
