@@ -23,8 +23,8 @@ def build(tmp_path, with_reference: bool) -> str:
     return exe
 
 
-def run(exe, *args):
-    p = subprocess.run([exe, *args], capture_output=True, text=True)
+def run(exe, *args, env=None):
+    p = subprocess.run([exe, *args], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout + p.stderr
     return p.stdout
 
@@ -47,3 +47,11 @@ def test_drop_in_compiles_against_reference_headers(mcrt, tmp_path):
 @pytest.mark.gpu
 def test_drop_in_renders_on_gpu(mcrt, gpu, tmp_path):
     assert "gpu: 0 failure(s)" in run(build(tmp_path, False), "--gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["0", "1"])
+def test_drop_in_renders_on_all_devices(mcrt, gpu, tmp_path, gather):
+    """MCRT_DEVICE=all routes the same TileRenderer::render call through mcrt_render_multi (every visible
+    device takes its cyclic share of the tile rows); the restated reference tests must still hold."""
+    assert "gpu: 0 failure(s)" in run(build(tmp_path, False), "--gpu", env={"MCRT_DEVICE": "all", "MCRT_GATHER": gather})
