@@ -148,9 +148,9 @@ def main() -> None:
     w, h, bounces, spp = cfg.width, cfg.height, cfg.maxBounces, cfg.samplesPerPixel
     sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
     # F frames in flight: frame k is rendered by scene handle / stream / buffers k mod F.  One frame's
-    # pipeline is a chain of ~16 dependent kernels with ~0.2 ms of fixed latency; a renderer that
-    # produces a sequence of frames overlaps the chain of one frame with the dense kernels of the
-    # next.  Every frame is rendered completely; `latency_ms` below is the one-frame-at-a-time figure.
+    # pipeline is a chain of 7 dependent launches, partly latency-bound; a renderer that produces a
+    # sequence of frames overlaps the chain of one frame with the dense kernels of the next.  Every
+    # frame is rendered completely; `latency_ms` below is the one-frame-at-a-time figure.
     F = max(1, args.frames_in_flight)
     # every handle plans its workspace against a budget of its own (default: a third of the HBM); F handles in
     # flight share the device, so each gets a share (a frame that needs more is cut into more passes)

@@ -361,7 +361,7 @@ RngKey rng_key_of(const RenderParams& p) {
     return k;
 }
 
-// MCRT_GRAPH=0 turns launch recording off (every render then issues its ~17 launches per lane)
+// MCRT_GRAPH=0 turns launch recording off (every render then issues its 7 launches per lane and pass itself)
 bool graphs_enabled() {
     static const bool v = [] {
         const char* e = std::getenv("MCRT_GRAPH");

@@ -14,8 +14,8 @@
 //                                     mt19937 stream — twisted inside the wave, no workgroup barrier — to HBM
 //   primary         persistent WGs    touched units: thread per sample, its draws, camera/lens ray, closest
 //                                     hit over the tile's mesh mask; misses write their sample colour, hits
-//                                     go to the level-0 queue.  Background tiles: thread per pixel, gradient,
-//                                     ordered sample sum, coalesced float4 / RGBA8 store
+//                                     become records at the front of the unit's slot range.  (Background tiles only when
+//                                     a pixel takes more than 24 draws: thread per pixel, gradient, ordered sample sum)
 //   bounce          1 lane / primary hit   reflection ray (geometry only: direction, hit point, normal) → closest
 //                                     hit → level-1 record; chains that end are marked
 //   chase           1 lane / level-1 record        the rest of the chain: reflect, closest hit, append, until the ray
@@ -1672,7 +1672,9 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
         const int batch_tiles = rows * p.shard.tiles_x;
         // (Clearing the counters from the pass's last kernel instead — the last workgroup of `resolve` to finish —
         // was tried: its 4096 returning atomics on one ticket word took 85 us, the ~88 ops/us of one address.)
-        hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 1) * 4, stream);
+        // all but the last four words (the sticky overflow word among them): a 16-byte multiple is ONE fill kernel,
+        // kCounterWords - 1 words were two
+        hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 4) * 4, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
                            p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);

@@ -27,7 +27,7 @@
 
 #define DEV __device__ __forceinline__
 // Shared (non-inlined) routines: one copy of the mesh loop and of the libm kernels in the code
-// object.  The fully inlined trace kernel was 85 KB of code — larger than the 64 KB instruction
+// object.  A fully inlined single render kernel (round 1's first design) was 85 KB of code — larger than the 64 KB instruction
 // cache CUs share — and ran instruction-fetch bound.
 #define DEVCALL __device__ __noinline__
 
@@ -102,7 +102,7 @@ struct Hit {
 };
 
 // Views of the flat blob.  SceneView reads everything from HBM (probes, rare sequential paths).
-// SceneViewLds is what the trace kernel uses: the two tables that candidates index PER LANE — the
+// SceneViewLds is what the ray-tracing kernels use: the two tables that candidates index PER LANE — the
 // alpha predicates and the face → texture table — live in LDS and are typed as LDS pointers, so
 // the lookups compile to ds_read (a pointer that may be either LDS or global becomes a flat load).
 #define MCRT_LDS __attribute__((address_space(3)))
@@ -447,7 +447,7 @@ DEV MeshData mesh_uniform(const SV& sc, int i) {
                     m.inv_z_sin, m.inv_x_cos, m.inv_x_sin,  m.fwd_x_cos,   m.fwd_x_sin, m.fwd_z_cos, m.fwd_z_sin,
                     (static_cast<unsigned long long>(m.group_hi) << 32) | m.group_lo};
 }
-// per-lane mesh index → the LDS mesh table (trace kernels) or vector loads from the blob
+// per-lane mesh index → the LDS mesh table (ray-tracing kernels) or vector loads from the blob
 template <class SV>
 DEV MeshData mesh_lane(const SV& sc, int i) {
     if constexpr (SV::kLds) {
@@ -877,7 +877,7 @@ template <class SV>
 DEV bool light_sample_visible(const SV& sc, V3 point, V3 normal, float d0, float d1) {
     return !in_shadow(sc, point, normal, light_sample_position(sc, point, d0, d1));
 }
-// isInShadow (:14-26) with the scene scan inlined at the call site (trace kernel phase C)
+// isInShadow (:14-26) with the scene scan inlined at the call site (hard-shadow rays of `lit` / `shadow`)
 template <class SV>
 DEV bool in_shadow_inline(const SV& sc, V3 point, V3 normal, V3 light) {
     V3 origin = point + normal * 1e-3f;
@@ -899,7 +899,7 @@ DEV bool in_shadow_masked(const SV& sc, V3 point, V3 normal, V3 light, unsigned 
     return any_hit_masked(sc, r, dist, cand);
 }
 
-// computeSoftShadow :28-60, sequential form (probes; the trace kernel spreads the samples over lanes)
+// computeSoftShadow :28-60, sequential form (probes; `lit` spreads the samples over lanes)
 template <class SV>
 DEV float soft_shadow(const SV& sc, V3 point, V3 normal, int samples, uint32_t seed, uint32_t* mt_storage) {
     V3 lpos = ld3(sc.hdr->light_pos);
@@ -1035,7 +1035,7 @@ constexpr int kMaxStack = 16;  // levels kept in per-lane scratch; deeper → pe
 
 // RayTracer::traceRay (:82-148) for a ray whose depth-`depth` hit is already known, as a loop:
 // walk down while rays keep hitting (level colours pushed), then fold back to front.  Sequential
-// per-lane form (probes); the trace kernel runs the same steps as workgroup phases.
+// per-lane form (probes); the render pipeline runs the same steps as kernels over hit records.
 template <class SV>
 DEV C4 trace_from_hit(const SV& sc, const mcrt_config& cfg, Ray ray, Hit hit, int depth,
                       C4* stack, uint32_t* mt_storage) {

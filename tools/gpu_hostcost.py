@@ -15,7 +15,7 @@ for (w, h, first, step) in ((64, 64, 0, 1), (1920, 1080, 0, 8), (1920, 1080, 0, 
     for _ in range(20):
         ds.render_device(cfg, out.data_ptr(), first, step, lay, st.cuda_stream)
     torch.cuda.synchronize()
-    # short burst on an idle queue: pure host cost of the ~17 launches of a render
+    # short burst on an idle queue: pure host cost of the launches of a render
     torch.cuda.synchronize()
     tb = time.perf_counter()
     for _ in range(8):
