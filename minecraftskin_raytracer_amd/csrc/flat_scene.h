@@ -21,6 +21,8 @@ enum : uint32_t {
     MESH_APPLY_X = 4u,  // |rotX| > 0.01  (rotatePoint gate, intersection.cpp:16)
     MESH_APPLY_Z = 8u,  // |rotZ| > 0.01  (intersection.cpp:26)
     MESH_EMPTY = 16u,   // tris.empty()   (intersection.cpp:205)
+    MESH_OPAQUE = 32u,  // no texel of its six faces has alpha == 0.0f: every slab hit is a hit (:311 never takes the
+                        // transparent branch) — shadow / AO rays skip the face, UV and texel work for such a mesh
 };
 
 // texture slot states for FlatMesh::tex_off

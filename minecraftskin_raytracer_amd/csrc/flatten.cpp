@@ -209,6 +209,15 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
                 f.tex_h[face] = d->textures[ti].height;
             }
         }
+        {  // MESH_OPAQUE: a null texture is opaque magenta, an empty one Color() with alpha 1
+            bool opaque = true;
+            for (int face = 0; face < 6 && opaque; ++face) {
+                if (f.tex_off[face] < 0) continue;
+                const int64_t n = static_cast<int64_t>(f.tex_w[face]) * f.tex_h[face];
+                for (int64_t k = 0; k < n && opaque; ++k) opaque = !(pool[4 * (f.tex_off[face] + k) + 3] == 0.0f);
+            }
+            if (opaque) f.flags |= MESH_OPAQUE;
+        }
 
         // Bounding sphere in world space: centre = (posed) box centre, radius = half diagonal, padded.
         {

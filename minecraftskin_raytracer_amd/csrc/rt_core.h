@@ -537,7 +537,9 @@ struct Cand {
 };
 
 // Phase 2: full evaluation of one mesh.  Returns true when it yields a hit with t < t_limit.
-template <class SV>
+// kAnyHit: the caller only asks whether (shadow and AO rays) — c is not filled, and a mesh without
+// transparent texels (MESH_OPAQUE: the inner layer of a skin) is decided by its slab test alone.
+template <bool kAnyHit, class SV>
 DEV bool mesh_candidate(const SV& sc, const MeshData& m, int mesh_index, const RayQ& world, float t_limit, Cand& c) {
     if (m.flags & MESH_EMPTY) return false;
     const bool rotated = SV::kPosed && (m.flags & MESH_ROTATED) != 0;
@@ -558,6 +560,11 @@ DEV bool mesh_candidate(const SV& sc, const MeshData& m, int mesh_index, const R
     }
     // un-posed meshes: local t IS the reported t, and the exit face is never nearer than the entry
     if (!rotated && !(tHit < t_limit)) return false;
+    if (kAnyHit && (m.flags & MESH_OPAQUE)) {  // texColor.a != 0 whatever the face and texel (:311): an ordinary hit at tHit
+        if (!rotated) return true;
+        const V3 pw = to_world(m, local.o + local.d * tHit);
+        return dot(pw - world.o, world.d) < t_limit;  // :402
+    }
 
     V3 hp = local.o + local.d * tHit;
     float t_front = tHit;
@@ -641,7 +648,7 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
         const int i = __builtin_ctzll(cand);
         cand &= cand - 1ull;
         Cand c;
-        if (mesh_candidate(sc, mesh_lane(sc, i), i, q, best.t, c)) {
+        if (mesh_candidate<false>(sc, mesh_lane(sc, i), i, q, best.t, c)) {
             best = c;
             best_mesh = i;
         }
@@ -649,7 +656,7 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
     if constexpr (!SV::kLds) {  // LDS views hold at most 64 meshes
         for (int i = 64; i < sc.n_meshes; ++i) {
             Cand c;
-            if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, best.t, c)) {
+            if (mesh_candidate<false>(sc, mesh_uniform(sc, i), i, q, best.t, c)) {
                 best = c;
                 best_mesh = i;
             }
@@ -692,12 +699,12 @@ DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
         const int i = __builtin_ctzll(cand);
         cand &= cand - 1ull;
         Cand c;
-        if (mesh_candidate(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
+        if (mesh_candidate<true>(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
     }
     if constexpr (!SV::kLds) {
         for (int i = 64; i < sc.n_meshes; ++i) {
             Cand c;
-            if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
+            if (mesh_candidate<true>(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
         }
     }
     return false;
@@ -711,12 +718,12 @@ DEV bool any_hit_masked(const SV& sc, const Ray& r, float limit, unsigned long l
         const int i = __builtin_ctzll(cand);
         cand &= cand - 1ull;
         Cand c;
-        if (mesh_candidate(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
+        if (mesh_candidate<true>(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
     }
     if constexpr (!SV::kLds) {
         for (int i = 64; i < sc.n_meshes; ++i) {
             Cand c;
-            if (mesh_candidate(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
+            if (mesh_candidate<true>(sc, mesh_uniform(sc, i), i, q, limit, c)) return true;
         }
     }
     return false;

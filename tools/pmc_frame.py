@@ -11,10 +11,11 @@ for l in open(sys.argv[1]).read().splitlines():
         parts = l.split()
         n = len(hdr)
         rows.append((' '.join(parts[1:-n]), dict(zip(hdr, map(float, parts[-n:])))))
-start = max(i for i, (n, d) in enumerate(rows) if 'plan_tiles' in n)
-frame = rows[start - 1:]
-end = next((i for i, (n, d) in enumerate(frame) if 'resolve' in n), len(frame) - 1)
-frame = frame[:end + 1]
+# the last COMPLETE frame: from the fill kernel ahead of a plan_tiles to the resolve that follows it
+ends = [i for i, (n, d) in enumerate(rows) if 'resolve' in n]
+end = ends[-1]
+start = max(i for i, (n, d) in enumerate(rows[:end]) if 'plan_tiles' in n)
+frame = rows[max(0, start - 1):end + 1]
 tf = tw = tv = 0.0
 for n, d in frame:
     f, w, v = d.get('FETCH_SIZE', 0), d.get('WRITE_SIZE', 0), d.get('SQ_INSTS_VALU', 0)

@@ -29,4 +29,4 @@ for SET in "${SETS[@]}"; do
   rocprofv3 --pmc $SET --output-format csv -d "$R/$OUT/pass$i" -- python3 "$R/$SCRIPT" "$@" > "$R/$OUT/pass$i.log" 2>&1 || echo "pass $i failed (see pass$i.log)"
 done
 python3 "$R/tools/pmc_summarize.py" "$R/$OUT" > "$R/$OUT/summary.txt"
-python3 "$R/tools/pmc_summarize.py" "$R/$OUT" --dispatches 20 | tee "$R/$OUT/dispatches.txt"
+python3 "$R/tools/pmc_summarize.py" "$R/$OUT" --dispatches 64 | tee "$R/$OUT/dispatches.txt"
