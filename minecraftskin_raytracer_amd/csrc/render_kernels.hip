@@ -1008,7 +1008,12 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const SceneView scg = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
     const Scope scope{0, 1};
-    if (no_entry_blocks(ws, scope)) return;  // before the collective staging
+    // ONE work list — the units' record ranges, then the dense queue in blocks of 256 — so that the three phases
+    // exist once in the code object (inlined per list they made 33 KB, half the instruction cache)
+    const uint32_t n_units = ws.counters[kCntUnits];
+    const uint32_t n_dense = dense_count(ws, scope);
+    const uint32_t n_items = n_units + (n_dense + kBlock - 1u) / kBlock;
+    if (blockIdx.x >= n_items) return;  // before the collective staging
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     constexpr bool kPosed = kView != kViewLdsUnposed;
     const int mode = shadow_mode(scg, p.cfg);
@@ -1026,7 +1031,16 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
     const V3 cam_pos = ld3(scg.hdr->cam_pos);
-    for_each_entry_block(ws, scope, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        uint32_t first, n;
+        if (item < n_units) {
+            first = ws.units[item].w;
+            n = ws.unit_hits[item];
+        } else {
+            const uint32_t k0 = (item - n_units) * kBlock;
+            first = ws.cap + k0;
+            n = min(static_cast<uint32_t>(kBlock), n_dense - k0);
+        }
         for (uint32_t r0 = 0; r0 < n; r0 += round) {  // uniform
             const uint32_t m = min(round, n - r0);
             const uint32_t base = first + r0;
@@ -1106,7 +1120,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                 ws.stack[static_cast<size_t>(r.depth) * ws.cap + r.root] = make_float4(c.r, c.g, c.b, c.a);  // plane-major: [depth][sample slot]
             }
         }
-    });
+    }
 }
 
 // ambient occlusion (raytracer.cpp:38-78, depth 0 only) as two stages over the primary hits:
