@@ -31,7 +31,9 @@ def make_case(seed: int):
     if g.random() < 0.3:
         sc.camera_fov = float(g.uniform(20, 110))
     w, h = int(g.integers(9, 150)), int(g.integers(9, 110))
-    kw = dict(width=w, height=h, maxBounces=int(g.integers(0, 7)), samplesPerPixel=int([1, 1, 2, 3, 4, 7][g.integers(0, 6)]),
+    # 13 spp: more than 24 draws per pixel (the tiles' streams go through HBM); 9 bounces: the general per-level variants
+    kw = dict(width=w, height=h, maxBounces=int([0, 1, 2, 3, 4, 5, 6, 3, 4, 9][g.integers(0, 10)]),
+              samplesPerPixel=int([1, 1, 2, 3, 4, 7, 4, 13][g.integers(0, 8)]),
               tileSize=int([1, 3, 8, 16, 32, 32, 50, 200][g.integers(0, 8)]))
     if g.random() < 0.25:
         kw["softShadows"] = False
