@@ -177,6 +177,10 @@ int mcrt_render_device(mcrt_scene* scene, const mcrt_config* cfg, int tile_row_f
  * idle set per device) for the next mcrt_scene_create / one-shot render on that device, because
  * allocating it dominates a single small render.  mcrt_trim() frees what is being kept. */
 void mcrt_trim(void);
+/* The library also keeps, per device that has rendered, a 128 MiB table of std::mt19937 seeding results
+ * (state word 397 for the seeds -2^24 .. 2^24-1, which is where the per-hit shadow seeds of a scene at the
+ * reference's scale lie): built once in ~2 ms, it replaces a 397-step recurrence per hit by one load, with
+ * identical results.  MCRT_SEED_TABLE=0 turns it off; mcrt_trim() frees it when no scene handle is left. */
 
 /* Waits for the scene's device work and reports an internal inconsistency of the last renders (the
  * workspace is sized for the tiles the host expects meshes to touch; the device flags a tile beyond

@@ -150,6 +150,8 @@ struct mcrt_scene {
     // back): no pin / unpin of a few KB of pageable memory per call
     void* staging = nullptr;
     size_t staging_bytes = 0;
+    const uint32_t* seed_table = nullptr;  // the device's table of mt19937 seeding results (kernels.h), or NULL
+    bool holds_seed_table = false;
 };
 
 namespace {
@@ -246,6 +248,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     Lane* s = &sc->lanes[li];
     std::memset(&p, 0, sizeof p);
     p.scene = static_cast<const uint8_t*>(sc->blob.ptr);
+    p.seed_table = sc->seed_table;
     p.cfg = *cfg;
     p.shard = make_shard(*cfg, first + li * step, step * n_lanes);
     p.shard.pack_first = li;
@@ -574,6 +577,58 @@ size_t workspace_bytes(const mcrt_scene* s) {
 std::mutex g_pool_mutex;
 std::vector<mcrt_scene*> g_pool;  // idle scene shells, at most one per device
 
+// ---- per-device seed tables (kernels.h: kSeedWindow words of mt[397] by seed; MCRT_SEED_TABLE=0 turns them off)
+struct SeedTable {
+    uint32_t* ptr = nullptr;
+    int users = 0;  // scene shells (live or pooled) that hold the pointer
+};
+std::mutex g_seed_mutex;
+std::vector<SeedTable> g_seed_tables;  // by device
+
+// the table of `device` (built on first use: one allocation, one ~2 ms kernel), or nullptr when turned off /
+// not available — the kernels then seed every hit by the recurrence
+const uint32_t* acquire_seed_table(int device) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("MCRT_SEED_TABLE");
+        return !e || std::atoi(e) != 0;
+    }();
+    if (!enabled) return nullptr;
+    std::lock_guard<std::mutex> lock(g_seed_mutex);
+    if (g_seed_tables.size() <= static_cast<size_t>(device)) g_seed_tables.resize(static_cast<size_t>(device) + 1);
+    SeedTable& t = g_seed_tables[static_cast<size_t>(device)];
+    if (!t.ptr) {
+        uint32_t* p = nullptr;
+        if (hipMalloc(&p, static_cast<size_t>(kSeedWindow) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (launch_build_seed_table(p, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
+        t.ptr = p;
+    }
+    ++t.users;
+    return t.ptr;
+}
+void release_seed_table(int device) {
+    std::lock_guard<std::mutex> lock(g_seed_mutex);
+    if (static_cast<size_t>(device) < g_seed_tables.size() && g_seed_tables[static_cast<size_t>(device)].users > 0)
+        --g_seed_tables[static_cast<size_t>(device)].users;
+}
+void free_unused_seed_tables() {  // mcrt_trim
+    std::lock_guard<std::mutex> lock(g_seed_mutex);
+    for (size_t d = 0; d < g_seed_tables.size(); ++d) {
+        SeedTable& t = g_seed_tables[d];
+        if (t.ptr && t.users == 0) {
+            (void)hipSetDevice(static_cast<int>(d));
+            (void)hipFree(t.ptr);
+            t.ptr = nullptr;
+        }
+    }
+}
+
 // keeps `s` for reuse unless it is large (MCRT_POOL_MB, default 49152 — a sixth of the MI355X's 288 GB: re-allocating
 // the tens of GB a 4K / 8K frame needs made each one-shot call of such a frame take about a second) or the
 // device already has one
@@ -685,6 +740,10 @@ int create_scene_from_blob(const std::vector<uint8_t>& b, int device, mcrt_scene
     s->have_last = false;  // a pooled shell was synchronised when its previous owner let go of it
     s->last_stream = nullptr;
     s->marks_used = 0;
+    if (!s->holds_seed_table) {
+        s->seed_table = acquire_seed_table(device);
+        s->holds_seed_table = s->seed_table != nullptr;
+    }
     const FlatHeader* fh = reinterpret_cast<const FlatHeader*>(b.data());
     const FlatMesh* fm = reinterpret_cast<const FlatMesh*>(b.data() + fh->mesh_offset);
     s->alpha_words = fh->alpha_words;
@@ -745,11 +804,13 @@ void mcrt_trim(void) {
         (void)hipSetDevice(s->device);
         destroy_scene_now(s);
     }
+    free_unused_seed_tables();
 }
 
 namespace {
 void destroy_scene_now(mcrt_scene* s) {
     if (!s) return;
+    if (s->holds_seed_table) release_seed_table(s->device);
     s->blob.release();  // the other buffers are released by their destructors below
     for (auto& ln : s->lanes) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);

@@ -70,8 +70,18 @@ struct WaveSpace {
     int stack_stride;       // maxBounces + 1 (at least 1)
 };
 
+// Seeding std::mt19937(seed) for a hit's light samples is a 397-step sequential recurrence whose only product
+// the truncated engine needs is the state word mt[397] — a pure function of the 32-bit seed.  The shadow seeds of
+// a scene at the reference's scale, (unsigned)(P·(12345, 67890, 11111) + depth·99999) (raytracer.cpp:110-112),
+// lie in a window around zero (|sum| < 4 M for the character scene): a table of mt[397] for the seeds
+// -2^24 .. 2^24 - 1 (wrapping) is 128 MB per device, built once with the same recurrence in ~2 ms, and replaces
+// the chain by one 4-byte load.  Seeds outside the window run the chain.
+constexpr uint32_t kSeedWindowHalf = 1u << 24;
+constexpr uint32_t kSeedWindow = 1u << 25;  // table entries: seed s at index s + kSeedWindowHalf (mod 2^32)
+
 struct RenderParams {
     const uint8_t* scene;  // flat blob in HBM
+    const uint32_t* seed_table;  // kSeedWindow words, or NULL: every hit seeds by the recurrence
     mcrt_config cfg;
     Shard shard;
     int layout;            // MCRT_LAYOUT_*
@@ -129,6 +139,8 @@ hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const flo
 hipError_t launch_assemble_frame(const mcrt_config& cfg, int world, const float* gathered, size_t rank_stride_pixels,
                                  float* frame, hipStream_t stream);
 hipError_t launch_quantize(const float* rgba, uint8_t* out, size_t n_pixels, hipStream_t stream);
+// fills table[i] = mt[397] of std::mt19937(i - kSeedWindowHalf) for i < kSeedWindow
+hipError_t launch_build_seed_table(uint32_t* table, hipStream_t stream);
 
 // probes
 hipError_t launch_probe_intersect(const uint8_t* scene, const float* rays, int n, mcrt_hit* out,

@@ -1051,7 +1051,12 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                     const RecordGeom g = load_geom(ws, posed, base + threadIdx.x);
                     const V3 P = g.p, N = g.n;
                     MtShort rng;
-                    rng.seed(shadow_seed(P, g.depth));
+                    const uint32_t seed = shadow_seed(P, g.depth);
+                    const uint32_t slot = seed + kSeedWindowHalf;  // wraps: the window is centred on seed 0
+                    if (p.seed_table && slot < kSeedWindow)
+                        rng.seed_known(seed, p.seed_table[slot]);  // mt[397] of this seed, from the device's table
+                    else
+                        rng.seed(seed);  // the 397-step recurrence
                     s_cand[threadIdx.x] = bundle_candidates<kPosed>(scg, P + N * 1e-3f, lpos, lradius);
                     const LightFrame frame = light_frame(scg, P);
                     float* dst = s_pos + static_cast<size_t>(threadIdx.x) * 3 * S;
@@ -1403,6 +1408,12 @@ __global__ void assemble_frame_kernel(mcrt_config cfg, int world, const float4* 
     frame[i] = gathered[static_cast<size_t>(rank) * rank_stride + (static_cast<size_t>(k) * T + ly) * W + x];
 }
 
+// the device's seed table (kernels.h): entry i = mt[397] of std::mt19937(i - kSeedWindowHalf)
+__global__ __launch_bounds__(256) void seed_table_kernel(uint32_t* __restrict__ table) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < kSeedWindow) table[i] = MtShort::word397(i - kSeedWindowHalf);
+}
+
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, size_t n) {  // image_writer.cpp:18-22
     size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1740,6 +1751,11 @@ hipError_t launch_quantize(const float* rgba, uint8_t* out, size_t n_pixels, hip
     if (n_pixels == 0) return hipSuccess;
     hipLaunchKernelGGL(quantize_kernel, dim3(static_cast<unsigned>((n_pixels + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const float4*>(rgba), reinterpret_cast<uchar4*>(out), n_pixels);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_seed_table(uint32_t* table, hipStream_t stream) {
+    hipLaunchKernelGGL(seed_table_kernel, dim3(kSeedWindow / 256u), dim3(256), 0, stream, table);
     return hipGetLastError();
 }
 

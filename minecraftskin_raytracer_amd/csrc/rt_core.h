@@ -196,11 +196,15 @@ constexpr int kMtShortMax = 227;  // draws available from the two-recurrence for
 struct MtShort {
     uint32_t lo, hi;  // mt[i], mt[i+397]
     uint32_t i;
-    DEV void seed(uint32_t s) {
-        lo = s;
+    DEV static uint32_t word397(uint32_t s) {  // mt[397] of a freshly seeded engine: the sequential part
         uint32_t x = s;
         for (uint32_t j = 1; j <= 397; ++j) x = mt_step(x, j);
-        hi = x;
+        return x;
+    }
+    DEV void seed(uint32_t s) { seed_known(s, word397(s)); }
+    DEV void seed_known(uint32_t s, uint32_t mt397) {  // mt397 = word397(s), e.g. from the device's seed table
+        lo = s;
+        hi = mt397;
         i = 0;
     }
     DEV float uniform() {

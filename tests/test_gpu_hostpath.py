@@ -139,3 +139,39 @@ def test_last_timings_split(mcrt, gpu):
     mcrt.TileRenderer.render(sd, cfg)
     t = mcrt.TileRenderer.lastTimings()
     assert t["total_ms"] > 0 and t["kernel_ms"] > 0 and t["total_ms"] >= t["flatten_ms"]
+
+
+@pytest.mark.parametrize("height", [0.0, 230.0, 247.0, 400.0, -300.0])
+def test_seed_table_window_and_recurrence_agree(mcrt, oracle, gpu, height):
+    """The device's table of mt19937 seeding results covers the shadow seeds -2^24 .. 2^24-1; a hit whose seed
+    (raytracer.cpp:110-112: P.y * 67890 dominates) falls outside runs the 397-step recurrence instead.  Boxes
+    placed so that the seeds lie inside the window, straddle its upper edge (y around 247), lie beyond it, or wrap
+    to the top of the unsigned range (negative sums)."""
+    tex = scenes.solid((0.8, 0.6, 0.4, 1.0))
+    meshes = [scenes.build_box(tex, (0.0, height, 0.0), (8.0, 12.0, 4.0)), scenes.build_box(tex, (7.0, height + 2.0, 1.0), (3.0, 10.0, 3.0))]
+    sc = scenes.simple_scene(meshes, light=(5.0, height + 30.0, 30.0), cam_pos=(0.0, height + 2.0, 40.0), cam_target=(0.0, height, 0.0))
+    sd = mcrt.SceneDesc(sc)
+    cfg = abi.Config(width=120, height=90, maxBounces=3, samplesPerPixel=2)
+    img = mcrt.TileRenderer.render(sd, cfg)
+    assert mcrt.TileRenderer.lastErrors() == []
+    scenes.assert_bit_equal(img, oracle.render(sd.ptr, cfg), f"boxes at y = {height}")
+
+
+def test_seed_table_can_be_turned_off(mcrt, gpu, tmp_path):
+    """MCRT_SEED_TABLE=0: every hit seeds by the recurrence; same frame.  (Read once per process → subprocess.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "render.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {repr(root)}); sys.path.insert(0, {repr(os.path.join(root, 'tests'))})\n"
+        "import minecraftskin_raytracer_amd as M, scenes\n"
+        "img = M.TileRenderer.render(scenes.skin_scene('S64', 6), M.Config(width=200, height=150, maxBounces=4, samplesPerPixel=4))\n"
+        "assert M.TileRenderer.lastErrors() == []\n"
+        "np.save(sys.argv[1], img)\n")
+    a, b = str(tmp_path / "on.npy"), str(tmp_path / "off.npy")
+    subprocess.check_call([sys.executable, str(script), a])
+    subprocess.check_call([sys.executable, str(script), b], env=dict(os.environ, MCRT_SEED_TABLE="0"))
+    assert np.array_equal(np.load(a).view(np.uint32), np.load(b).view(np.uint32))
