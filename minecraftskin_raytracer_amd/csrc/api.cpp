@@ -1188,6 +1188,7 @@ int mcrt_render_tile(const mcrt_scene_desc* desc, const mcrt_config* cfg, int ti
     int rc = mcrt_scene_create(desc, device, &s);
     if (rc != MCRT_OK) return rc;
     // render the tile row that contains the tile (a shard of exactly one row), packed
+    s->forced_lanes = 1;  // one stream, like every host-buffer entry point (see render_to_host)
     const int th = tile_row_height(*cfg, row);
     const size_t row_floats = static_cast<size_t>(th) * cfg->width * 4;
     std::vector<float> host(row_floats);
@@ -1216,6 +1217,7 @@ int mcrt_render_png(const mcrt_scene_desc* desc, const mcrt_config* cfg, const c
     mcrt_scene* s = nullptr;
     int rc = mcrt_scene_create(desc, device, &s);
     if (rc != MCRT_OK) return rc;
+    s->forced_lanes = 1;  // one stream, like every host-buffer entry point (see render_to_host)
     const size_t npix = static_cast<size_t>(cfg->width) * cfg->height;
     std::vector<uint8_t> host(npix * 4);
     hipError_t e = s->frame.reserve(npix * 4);
