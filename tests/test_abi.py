@@ -227,3 +227,41 @@ def test_bounce_limit_is_checked_before_any_device_work(mcrt):
     assert lib.mcrt_render_multi(sd.ptr, C.byref(cfg), abi.fptr(out), C.cast(None, abi.PROGRESS_FN), None, None, 0, 0) == abi.MCRT_ERR_INVALID
     assert lib.mcrt_render_tile(sd.ptr, C.byref(cfg), 0, abi.fptr(out), 0) == abi.MCRT_ERR_INVALID
     assert lib.mcrt_render_png(sd.ptr, C.byref(cfg), b"/tmp/never_written.png", 0) == abi.MCRT_ERR_INVALID
+
+
+def test_scene_desc_pointer_keeps_its_owner_alive(oracle):
+    """`.ptr` of a temporary description stays valid for as long as the pointer is referenced (round 1 crashed in
+    the oracle when a test passed `skin_scene(...).ptr` and the description had been collected)."""
+    import gc
+
+    p = scenes.skin_scene("S64", 3).ptr  # the SceneDesc itself is a temporary
+    q = scenes.skin_scene("S32", 1).ptr
+    gc.collect()
+    assert p.contents.n_meshes == 12 and q.contents.n_meshes == 7
+    img = oracle.render(p, abi.Config(width=24, height=18, maxBounces=1))
+    assert img.shape == (18, 24, 4) and np.isfinite(img).all()
+
+
+def test_render_entry_points_without_a_device(mcrt):
+    """No HIP device: every way of naming devices records ONE TileError{-1, ...} and returns the Color() image
+    (tile_renderer.cpp:158-166: render() never throws for render failures)."""
+    if mcrt.device_count() > 0:
+        pytest.skip("for boxes without a GPU")
+    sd = scenes.skin_scene("S64", 0)
+    cfg = abi.Config(width=32, height=16)
+    for device in (0, "all", -1, [0, 0]):
+        img = mcrt.TileRenderer.render(sd, cfg, device=device)
+        errs = mcrt.TileRenderer.lastErrors()
+        assert len(errs) == 1 and errs[0][0] == -1 and "device" in errs[0][1].lower(), (device, errs)
+        assert img.shape == (16, 32, 4) and (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+
+
+def test_render_out_argument_is_validated(mcrt):
+    sd = scenes.skin_scene("S64", 0)
+    cfg = abi.Config(width=32, height=16)
+    for bad in (np.zeros((16, 32, 3), np.float32), np.zeros((16, 32, 4), np.float64), np.zeros((32, 16, 4), np.float32),
+                np.zeros((16, 64, 4), np.float32)[:, ::2]):
+        with pytest.raises(ValueError):
+            mcrt.TileRenderer.render(sd, cfg, out=bad)
+    with pytest.raises(ValueError):
+        mcrt.TileRenderer.render(sd, cfg, device="some")
