@@ -16,8 +16,9 @@
 //                                     hit over the tile's mesh mask; misses write their sample colour, hits
 //                                     become records at the front of the unit's slot range.  (Background tiles only when
 //                                     a pixel takes more than 24 draws: thread per pixel, gradient, ordered sample sum)
-//   bounce          1 lane / primary hit   reflection ray (geometry only: direction, hit point, normal) → closest
-//                                     hit → level-1 record; chains that end are marked
+//                                     ... and, packed on the block's first threads, the reflection ray of every
+//                                     primary hit (geometry only: direction, hit point, normal) → closest hit →
+//                                     level-1 record; chains that end are marked
 //   chase           1 lane / level-1 record        the rest of the chain: reflect, closest hit, append, until the ray
 //                                     misses or maxBounces is reached (~10 % go on per level)
 //   ... then ONCE over the records of ALL levels (550 k + 55 k + 5 k + ... at 1080p / 4 spp):
@@ -30,7 +31,8 @@
 //   resolve         1 lane / pixel    folds each sample's chain back to front, ordered sum of the pixel's sample
 //                                     colours (float addition order is part of the result), coalesced float4 / RGBA8 store
 //   (general variants — per-hit RNG streams longer than 227 draws, or more than kFlatMaxBounces bounces — run
-//   light_samples / shadow / level_shade once per recursion level instead of bounce .. lit)
+//   light_samples / shadow / level_shade once per recursion level instead of chase and lit, and `primary` traces no
+//   reflection rays)
 // Records live in HBM as SoA float4 arrays.  Every unit owns a fixed slot range (its samples); its
 // primary hits are compacted to the front of that range with an LDS prefix sum and a per-unit count —
 // NO global atomics on the hot path (a returning atomic on one word sustains only ~88 ops/us on this
@@ -46,7 +48,10 @@ using namespace rt;
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 256;        // work items per chunk: one per thread
-constexpr int kPrimaryGrid = 1024; // persistent primary workgroups (4 per CU)
+#ifndef MCRT_PRIMARY_GRID
+#define MCRT_PRIMARY_GRID 1024
+#endif
+constexpr int kPrimaryGrid = MCRT_PRIMARY_GRID; // persistent primary workgroups (4 per CU)
 constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
 
 // ---------------------------------------------------------------------------------------------
@@ -311,6 +316,13 @@ struct ViewSel<kViewHbm> {
 // queue helpers
 // ---------------------------------------------------------------------------------------------
 // counters[0]: number of planned units (one atomic add per touched tile, in plan_tiles)
+constexpr int kCntDense = 8;              // general variants: counters[kCntDense + L] = entries of level L >= 1
+constexpr int kCntDeep1 = kCntDense + 1;  // flat pipeline: level-1 records
+constexpr int kCntDeep2 = 2;              // flat pipeline: records of levels >= 2
+// WaveSpace::end of a sample whose chain has ended: (records of the chain << 1) | stopped at maxBounces
+__device__ __forceinline__ uint32_t chain_code(int records, bool stopped_at_max) {
+    return (static_cast<uint32_t>(records) << 1) | (stopped_at_max ? 1u : 0u);
+}
 constexpr int kCntUnits = 0;
 constexpr int kCntTiles = 1;     // touched tiles of the batch so far
 constexpr int kCntOverflow = kCounterWords - 1;  // set if more tiles are touched than the host planned for (a bug: the host
@@ -503,6 +515,8 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                                                          float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p,
                                                          const int tile_base, const int n_tiles) {
     __shared__ int s_wcnt[kBlock / 64];
+    __shared__ float4 s_bd[kBlock], s_bp[kBlock], s_bn[kBlock];  // the chunk's primary hits, packed, for their reflection rays
+    __shared__ uint32_t s_out_base;
     extern __shared__ __align__(16) unsigned char s_dyn[];
 
     const SceneView scg = view_of(scene_blob);
@@ -510,6 +524,11 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
     const WaveSpace& ws = p.ws;
     const uint32_t n_units = ws.counters[kCntUnits];
     if (p.bg_in_plan && blockIdx.x >= n_units) return;  // nothing for this workgroup: leave before the collective staging
+    // flat pipeline: the reflection ray of every primary hit (raytracer.cpp:133-139) is traced right here, by the first
+    // `total` threads of the block on the chunk's packed hits (as a launch of its own this stage re-read every record:
+    // 39 + 28 us became 59 us)
+    const bool bounce_here = p.flat && cfg.max_bounces >= 1;
+    const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     const int tid = threadIdx.x;
     const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
@@ -571,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                     is_hit = true;
                 if (!is_hit) ws.scol[sample_slot] = make_float4(col.r, col.g, col.b, col.a);  // final for misses
                 // 0: the colour is in scol (general variants: `level_shade` puts the hits' colours there too).  Flat
-                // pipeline: `bounce` / `chase` overwrite a hit's word with its chain's end code — unless
+                // pipeline: the second phase below / `chase` overwrite a hit's word with its chain's end code — unless
                 // maxBounces is 0 and the chain is its primary hit alone.
                 ws.end[sample_slot] = (is_hit && p.flat && cfg.max_bounces == 0) ? 3u : 0u;
             }
@@ -582,11 +601,42 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                 const uint32_t e = slot_base + unit_hits + static_cast<uint32_t>(rank);
                 // root of the chain = its sample's colour slot
                 if (p.flat)
-                    push_record(ws, p.scene_posed != 0, e, ray, hit, sample_slot, 0, dof);
+                    push_record(ws, posed, e, ray, hit, sample_slot, 0, dof);
                 else
                     push_entry(ws, 0, e, ray, hit, sample_slot, 0);
+                if (bounce_here) {
+                    s_bd[rank] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(sample_slot));
+                    s_bp[rank] = make_float4(hit.p.x, hit.p.y, hit.p.z, 0.0f);
+                    s_bn[rank] = make_float4(hit.n.x, hit.n.y, hit.n.z, 0.0f);
+                }
             }
             unit_hits += static_cast<uint32_t>(total);
+            if (bounce_here && total > 0) {  // uniform
+                __syncthreads();
+                bool next_hit = false;
+                Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
+                Hit nhit;
+                nhit.hit = false;
+                uint32_t root = 0;
+                if (tid < total) {
+                    const float4 bd = s_bd[tid], bp = s_bp[tid], bn = s_bn[tid];
+                    root = __float_as_uint(bd.w);
+                    nray = reflect_ray(mk(bd.x, bd.y, bd.z), mk(bp.x, bp.y, bp.z), mk(bn.x, bn.y, bn.z));
+                    nhit = hit_scene(sc, nray, ~0ull);
+                    if (nhit.hit)
+                        next_hit = true;
+                    else
+                        ws.end[root] = chain_code(1, false);  // bounced ray missed → flat background (raytracer.cpp:94-102)
+                }
+                int survivors = 0;
+                const int srank = block_rank(next_hit, s_wcnt, survivors);
+                if (survivors > 0) {  // uniform
+                    if (tid == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep1], static_cast<uint32_t>(survivors));
+                    __syncthreads();
+                    if (next_hit) push_record(ws, posed, ws.cap + s_out_base + static_cast<uint32_t>(srank), nray, nhit, root, 1, true);
+                }
+                __syncthreads();  // s_bd .. s_out_base are reused by the next chunk
+            }
         }
         if (tid == 0) ws.unit_hits[u] = unit_hits;
     }
@@ -630,22 +680,19 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
 // ---------------------------------------------------------------------------------------------
 // The recursion of RayTracer::traceRay (raytracer.cpp:82-148) as a FLAT pipeline.  The reflection ray
 // of a hit depends on geometry only — direction, hit point, normal (:133-139) — not on the colour
-// of the hit.  So the chain of hits below a primary hit is chased first (`bounce`: every primary hit's
-// reflection ray; `chase`: the ~10 % that hit again, followed to their end), every hit of every level
-// becoming one *record*; then the expensive stages — light samples, shadow rays, shading — run ONCE over
+// of the hit.  So the chain of hits below a primary hit is chased first (`primary`'s second phase: every
+// primary hit's reflection ray; `chase`: the ~10 % that hit again, followed to their end), every hit of every
+// level becoming one *record*; then the expensive stages — light samples, shadow rays, shading — run ONCE over
 // all records of all levels, and `resolve` folds each chain's level colours back to front (:143-147)
 // while it sums the pixel's samples.  One launch set per level cost ~40 us of dependent latency per
 // level whatever it held (550 k, 55 k, 5 k, 500, 50 records at 1080p / 4 spp).
 //
 // Primary hits sit at the front of each unit's slot range (count per unit, no atomics).  Deeper records
 // are appended densely behind index `cap` with ONE workgroup-aggregated atomic per 256-entry block:
-// level 1 by `bounce` (counter kCntDeep1), levels >= 2 by `chase` behind them (kCntDeep2).
+// level 1 by `primary` (counter kCntDeep1), levels >= 2 by `chase` behind them (kCntDeep2).
 // The general variants (per-hit RNG streams longer than the register engine, or more bounces than
 // the flat record arrays are laid out for) keep one launch set per level with ping-pong queues.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCntDense = 8;              // general variants: counters[kCntDense + L] = entries of level L >= 1
-constexpr int kCntDeep1 = kCntDense + 1;  // flat: level-1 records
-constexpr int kCntDeep2 = 2;              // flat: records of levels >= 2
 
 // which records a queue kernel walks: flat — every record of the batch; else — the entries of `level`
 struct Scope {
@@ -712,59 +759,10 @@ __device__ __forceinline__ Record load_record(const WaveSpace& ws, int par, uint
     }
     return r;
 }
-__device__ __forceinline__ uint32_t chain_code(int records, bool stopped_at_max) {
-    return (static_cast<uint32_t>(records) << 1) | (stopped_at_max ? 1u : 0u);
-}
 
-// ---------------------------------------------------------------------------------------------
-// bounce: the reflection ray of every primary hit (raytracer.cpp:133-139) and its closest hit →
-// level-1 records; chains that end here get their `end` code.
-// ---------------------------------------------------------------------------------------------
 #ifndef MCRT_BOUNCE_WAVES
 #define MCRT_BOUNCE_WAVES 4
 #endif
-template <int kView>
-__global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void bounce_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
-    __shared__ int s_wcnt[kBlock / 64];
-    __shared__ uint32_t s_out_base;
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    const SceneView scg = view_of(scene_blob);
-    const WaveSpace& ws = p.ws;
-    if (blockIdx.x >= ws.counters[kCntUnits]) return;  // before the collective staging
-    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
-    const int max_b = p.cfg.max_bounces;
-    const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
-    for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
-        bool next_hit = false;
-        Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
-        Hit nhit;
-        nhit.hit = false;
-        uint32_t root = 0;
-        if (threadIdx.x < n) {
-            const RecordGeom r = load_geom(ws, posed, first + threadIdx.x);
-            root = r.root;
-            if (max_b < 1) {
-                ws.end[root] = chain_code(1, true);
-            } else {
-                nray = reflect_ray(r.d, r.p, r.n);
-                nhit = hit_scene(sc, nray, ~0ull);
-                if (nhit.hit)
-                    next_hit = true;
-                else
-                    ws.end[root] = chain_code(1, false);  // bounced ray missed → flat background (raytracer.cpp:94-102)
-            }
-        }
-        int total = 0;
-        const int rank = block_rank(next_hit, s_wcnt, total);
-        if (total > 0) {  // uniform
-            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep1], static_cast<uint32_t>(total));
-            __syncthreads();
-            if (next_hit) push_record(ws, posed, ws.cap + s_out_base + static_cast<uint32_t>(rank), nray, nhit, root, 1, true);
-            __syncthreads();
-        }
-    });
-}
-
 // ---------------------------------------------------------------------------------------------
 // chase: every level-1 record's chain followed to its end, a lane per chain — reflect, closest hit,
 // append the record — until the ray misses or the chain reaches maxBounces.  ~10 % of the lanes go on per
@@ -1666,10 +1664,8 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : kQueueGrid;
     }();
-    if (levels >= 2) {  // the chains below the primary hits (maxBounces = 0: `primary` has marked them already)
-        hipLaunchKernelGGL(bounce_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
+    if (levels >= 2)  // the chains below the level-1 records `primary` found (maxBounces = 0: it has marked the chains already)
         hipLaunchKernelGGL(chase_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
-    }
     if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
         hipLaunchKernelGGL(ao_dirs_kernel<posed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
