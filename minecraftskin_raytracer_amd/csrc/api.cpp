@@ -249,6 +249,13 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     std::memset(&p, 0, sizeof p);
     p.scene = static_cast<const uint8_t*>(sc->blob.ptr);
     p.seed_table = sc->seed_table;
+    {
+        static const bool decisions = [] {  // development knob: MCRT_BUNDLE_DECISIONS=0 traces every hit's shadow rays
+            const char* e = std::getenv("MCRT_BUNDLE_DECISIONS");
+            return !(e && e[0] == '0');
+        }();
+        p.bundle_decisions = decisions ? 1 : 0;
+    }
     p.cfg = *cfg;
     p.shard = make_shard(*cfg, first + li * step, step * n_lanes);
     p.shard.pack_first = li;

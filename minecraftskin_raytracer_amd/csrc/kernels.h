@@ -102,6 +102,8 @@ struct RenderParams {
     int lit_lds_offset;    // `lit`: byte offset of that area in dynamic LDS (behind the scene tables, 16-aligned)
     int lit_lds_bytes;     // `lit`: its size
     int flat;              // 1: flat pipeline (all levels' records shaded at once); 0: general variants, one launch set per level
+    int bundle_decisions;  // `lit`: 1 — a hit whose whole bundle of shadow rays is decided (rt::bundle_decide) draws no light
+                           //    samples and traces no rays; 0 (MCRT_BUNDLE_DECISIONS=0) — every hit's rays are traced
 };
 
 Shard make_shard(const mcrt_config& cfg, int first, int step);

@@ -1002,7 +1002,11 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
 #endif
 template <int kView>
 __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
-    extern __shared__ __align__(16) unsigned char s_dyn[];  // [scene tables][masks][positions: lit_round x S x 3 floats][lit counts]
+    extern __shared__ __align__(16) unsigned char s_dyn[];  // [scene tables][masks][positions: lit_round x S x 3 floats][lit counts][undecided list]
+    __shared__ int s_wcnt[kBlock / 64];
+#ifdef MCRT_DECIDE_CHECK  // verification build (tools/decide_check.sh): every decided record is traced as well
+    __shared__ uint32_t s_stat[kBlock];
+#endif
     const SceneView scg = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
     const Scope scope{0, 1};
@@ -1022,6 +1026,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_dyn + p.lit_lds_offset);  // 16-aligned
     float* s_pos = reinterpret_cast<float*>(s_cand + round);
     uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + static_cast<size_t>(round) * pairs_per_hit * 3);
+    uint32_t* s_und = s_lit + round;  // the round's undecided records, packed
     const V3 lpos = ld3(scg.hdr->light_pos);
     const float lradius = scg.hdr->light_radius;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1042,12 +1047,41 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
         for (uint32_t r0 = 0; r0 < n; r0 += round) {  // uniform
             const uint32_t m = min(round, n - r0);
             const uint32_t base = first + r0;
-            // ---- phase A: a lane per record
+            // ---- phase A1: a lane per record — the bundle mask, and whether the whole bundle is decided (rt::bundle_decide)
+            bool undecided = false;
             if (threadIdx.x < m) {
-                if (!pow2) s_lit[threadIdx.x] = 0u;  // (this thread's own read of it in phase C came first)
                 if (mode == SHADOW_SOFT) {
                     const RecordGeom g = load_geom(ws, posed, base + threadIdx.x);
-                    const V3 P = g.p, N = g.n;
+                    const V3 O = g.p + g.n * 1e-3f;
+                    unsigned long long cand = bundle_candidates<kPosed>(scg, O, lpos, lradius);
+                    const int known = p.bundle_decisions ? bundle_decide(sc, O, lpos, lradius, S, cand) : -1;
+                    undecided = known < 0;
+#ifdef MCRT_DECIDE_CHECK
+                    s_stat[threadIdx.x] = static_cast<uint32_t>(known + 1);
+                    undecided = true;
+                    cand = bundle_candidates<kPosed>(scg, O, lpos, lradius);
+#endif
+                    s_cand[threadIdx.x] = cand;
+                    s_lit[threadIdx.x] = undecided ? 0u : static_cast<uint32_t>(known);
+                } else {
+                    s_lit[threadIdx.x] = 0u;
+                }
+            }
+            uint32_t n_und = m;  // records whose rays are traced
+            if (mode == SHADOW_SOFT) {
+                int total = 0;
+                const int rank = block_rank(undecided, s_wcnt, total);
+                if (undecided) s_und[rank] = threadIdx.x;
+                n_und = static_cast<uint32_t>(total);
+                if (n_und == 0u) {  // uniform: no ray of this round needs tracing
+                    __syncthreads();
+                    goto shade_round;
+                }
+                __syncthreads();
+                // ---- phase A2: a lane per undecided record — its mt19937 stream and the S disk sample positions
+                if (threadIdx.x < n_und) {
+                    const RecordGeom g = load_geom(ws, posed, base + s_und[threadIdx.x]);
+                    const V3 P = g.p;
                     MtShort rng;
                     const uint32_t seed = shadow_seed(P, g.depth);
                     const uint32_t slot = seed + kSeedWindowHalf;  // wraps: the window is centred on seed 0
@@ -1055,7 +1089,6 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                         rng.seed_known(seed, p.seed_table[slot]);  // mt[397] of this seed, from the device's table
                     else
                         rng.seed(seed);  // the 397-step recurrence
-                    s_cand[threadIdx.x] = bundle_candidates<kPosed>(scg, P + N * 1e-3f, lpos, lradius);
                     const LightFrame frame = light_frame(scg, P);
                     float* dst = s_pos + static_cast<size_t>(threadIdx.x) * 3 * S;
                     for (int i = 0; i < S; ++i) {
@@ -1069,33 +1102,37 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                 }
             }
             __syncthreads();
-            // ---- phase B: a lane per (record, light sample); every lane of a wave runs the same number of turns (ballot inside)
-            const uint32_t total = m * pairs_per_hit;
-            for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) {
-                const uint32_t q = q0 + lane;
-                bool visible = false;
-                uint32_t k = 0;
-                if (q < total) {
-                    k = q / pairs_per_hit;
-                    V3 P, N;
-                    load_point_normal(ws, posed, base + k, P, N);
-                    if (mode == SHADOW_HARD) N = normalize(N);
-                    if (mode == SHADOW_SOFT)
-                        visible = !in_shadow_masked(sc, P, N, ld3(s_pos + static_cast<size_t>(q) * 3), s_cand[k]);
-                    else
-                        visible = !in_shadow_inline(sc, P, N, lpos);
-                }
-                if (pow2) {
-                    const unsigned long long bal = __ballot(visible);
-                    if (q < total && (lane & (pairs_per_hit - 1u)) == 0u) {
-                        const unsigned long long grp = (pairs_per_hit == 64u) ? bal : ((bal >> lane) & ((1ull << pairs_per_hit) - 1ull));
-                        s_lit[k] = static_cast<uint32_t>(__popcll(grp));
+            {
+                // ---- phase B: a lane per (undecided record, light sample); every lane of a wave runs the same number of turns (ballot inside)
+                const uint32_t total = n_und * pairs_per_hit;
+                for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) {
+                    const uint32_t q = q0 + lane;
+                    bool visible = false;
+                    uint32_t k = 0;
+                    if (q < total) {
+                        const uint32_t j = q / pairs_per_hit;
+                        k = (mode == SHADOW_SOFT) ? s_und[j] : j;
+                        V3 P, N;
+                        load_point_normal(ws, posed, base + k, P, N);
+                        if (mode == SHADOW_HARD) N = normalize(N);
+                        if (mode == SHADOW_SOFT)
+                            visible = !in_shadow_masked(sc, P, N, ld3(s_pos + static_cast<size_t>(q) * 3), s_cand[k]);
+                        else
+                            visible = !in_shadow_inline(sc, P, N, lpos);
                     }
-                } else if (visible) {
-                    atomicAdd(&s_lit[k], 1u);
+                    if (pow2) {
+                        const unsigned long long bal = __ballot(visible);
+                        if (q < total && (lane & (pairs_per_hit - 1u)) == 0u) {
+                            const unsigned long long grp = (pairs_per_hit == 64u) ? bal : ((bal >> lane) & ((1ull << pairs_per_hit) - 1ull));
+                            s_lit[k] = static_cast<uint32_t>(__popcll(grp));
+                        }
+                    } else if (visible) {
+                        atomicAdd(&s_lit[k], 1u);
+                    }
                 }
             }
             __syncthreads();  // the counts are complete; the next round may overwrite the positions
+        shade_round:
             // ---- phase C: a lane per record
             if (threadIdx.x < m) {
                 const uint32_t e = base + threadIdx.x;
@@ -1111,6 +1148,16 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                     origin = mk(qo.x, qo.y, qo.z);
                 }
                 const uint32_t lit = s_lit[threadIdx.x];
+#ifdef MCRT_DECIDE_CHECK
+                if (mode == SHADOW_SOFT) {  // counters 2000..: undecided, decided (all shadowed / all lit), contradicted by the traced rays
+                    const uint32_t st = s_stat[threadIdx.x];
+                    atomicAdd(&ws.counters[2000 + (st == 0u ? 0 : (st == 1u ? 1 : 2))], 1u);
+                    if (st != 0u && st - 1u != lit) {
+                        atomicAdd(&ws.counters[2003], 1u);
+                        printf("DECIDE_CHECK decided %u traced %u  P %.9g %.9g %.9g N %g %g %g depth %d\n", st - 1u, lit, r.p.x, r.p.y, r.p.z, r.n.x, r.n.y, r.n.z, r.depth);
+                    }
+                }
+#endif
                 const float vis = (mode == SHADOW_SOFT) ? static_cast<float>(lit) / static_cast<float>(S) : (lit ? 1.0f : 0.0f);
                 C4 c = shade(scg, hit, normalize(origin - hit.p), vis);
                 if (cfg.ao_enabled && r.depth == 0) {  // occluded count from the ao stage (e < cap: a primary hit)
@@ -1343,6 +1390,11 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
         store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
                     make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp));
     };
+#ifdef MCRT_DECIDE_CHECK
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("DECIDE_CHECK records: %u undecided, %u decided all-shadowed, %u decided all-lit, %u CONTRADICTED\n", ws.counters[2000], ws.counters[2001],
+               ws.counters[2002], ws.counters[2003]);
+#endif
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint4 d = ws.units[u];
         const TileGeom tg = tile_of(p, static_cast<int>(d.x));
@@ -1566,11 +1618,11 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     // `lit`: records per round such that their sample positions, masks and counts fit its LDS budget
     {
         const size_t pairs = S ? S : 1;
-        size_t round = kLitLdsBytes / (12 * pairs + 12);
+        size_t round = kLitLdsBytes / (12 * pairs + 16);
         if (round > static_cast<size_t>(kBlock)) round = kBlock;
         if (round < 1) round = 1;
         p.lit_round = static_cast<int>(round);
-        p.lit_lds_bytes = static_cast<int>(round * (12 * pairs + 12));
+        p.lit_lds_bytes = static_cast<int>(round * (12 * pairs + 16));
         p.lit_lds_offset = static_cast<int>((scene_table_bytes(p) + 15) & ~static_cast<size_t>(15));
     }
     const int owned = p.shard.owned_rows;

@@ -796,6 +796,200 @@ DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
     return cand;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Whole-bundle decisions.  Most hits of a frame are lit by ALL of their S light samples or by NONE: the S shadow
+// rays leave one origin towards a small disk far away, so against the boxes around the origin they all do the same
+// thing — move away from the face they start on, or leave the enclosing outer-layer box through one and the same
+// texel.  bundle_decide_mesh proves such an outcome for one mesh and EVERY ray the hit can cast (every target T
+// with |T - L| <= R), from interval bounds with margins far above the float error of the per-ray arithmetic
+// (intersection.cpp:200-371, shading.cpp:14-26), or says BUNDLE_UNKNOWN.  A hit whose candidates are all decided
+// needs no light samples at all: no mt19937 stream, no sin/cos, no shadow rays — its lit count is 0 or S.
+// What a decision rests on:
+//   moving away   origin beyond a face on one axis and no target on the box's side of it: both slab distances
+//                 of that axis are negative (or the axis is parallel and outside) — an exact sign argument;
+//   one face      the origin lies inside the box (exit face) or beyond exactly one face with every ray heading
+//                 inwards (entry face): the points where the rays cross that face's plane lie in a rectangle
+//                 [X_lo, X_hi] (the perspective image of the target box); if it is inside the face with margin, every
+//                 ray reports that face, and if the corner texels of the rectangle agree (<= 2 x 2 texels; the float
+//                 u,v → texel pipeline is monotone per coordinate, so every ray's texel lies between the corners')
+//                 on `alpha == 0`, the face decides: opaque → hit at t < distance (checked), transparent →
+//                 miss (an outer-layer ENTRY face would go on to the exit face: left undecided);
+//   passing by    beyond one face and the rectangle is outside the face with margin: the ray has left another
+//                 slab before it enters this one → miss.
+// A posed mesh is examined in its own frame, like the reference examines it (intersection.cpp:384-395), with the
+// rotation's float error added to the bounds.  Origins beyond two faces, rectangles that straddle texels or face
+// edges, boxes without thickness on the crossed axis: BUNDLE_UNKNOWN — those meshes stay in the hit's mask and
+// its rays are traced.
+// ---------------------------------------------------------------------------------------------
+enum : int { BUNDLE_UNKNOWN = 0, BUNDLE_MISS = 1, BUNDLE_HIT = 2 };
+struct BundleGeom {
+    V3 O;                    // point + normal * 1e-3f, the origin isInShadow forms (shading.cpp:15)
+    V3 nlo, nhi;             // bounds of T - O per axis over every target
+    float dist_lo, dist_hi;  // bounds of |T - O|
+    float omax;              // max |O| component
+    bool ok;
+};
+DEV float max3abs(V3 v) { return smax(smax(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }
+// rot_slop: 0, or (posed meshes, O and L in the mesh's frame) the relative error of the reference's rotated ray
+// direction (rotateDir + normalize, intersection.cpp:388-393) against the rotated difference formed here
+DEV BundleGeom bundle_geom(V3 O, V3 L, float R, float rot_slop) {
+    BundleGeom g;
+    g.O = O;
+    g.omax = max3abs(O);
+    const V3 D = L - O;
+    // |T - L| <= R (1 + 2e-6) componentwise and in length (unit frame vectors, |sin|,|cos| <= 1); slop: the roundings
+    // of L + offset, of the differences below and of the reference's own T - O
+    const float Rb = R * 1.001f + 2e-6f * (max3abs(L) + g.omax + R) + rot_slop * (max3abs(D) + R) + 1e-30f;
+    g.nlo = mk(D.x - Rb, D.y - Rb, D.z - Rb);
+    g.nhi = mk(D.x + Rb, D.y + Rb, D.z + Rb);
+    const float dc = __builtin_sqrtf(dot(D, D));
+    g.dist_lo = dc * (1.0f - 1e-5f) - Rb;
+    g.dist_hi = dc * (1.0f + 1e-5f) + Rb;
+    g.ok = g.dist_lo > 1e-3f && g.dist_hi < 1e18f;  // isInShadow's `distToLight < 1e-6` exit is never taken
+    return g;
+}
+template <class SV>
+DEV int bundle_decide_mesh(const SV& sc, const MeshData& m, int mesh_index, const BundleGeom& gw, V3 Lw, float R) {
+    if (m.flags & MESH_EMPTY) return BUNDLE_MISS;  // intersection.cpp:205
+    BundleGeom g = gw;
+    if (SV::kPosed && (m.flags & MESH_ROTATED)) {
+        // a posed mesh is tested in its own frame (intersection.cpp:384-395).  The origin is rotated exactly as
+        // to_local does (the same bits as the reference's localOrigin); the rotation is rigid, so the targets stay
+        // within R of the rotated light centre and every distance keeps its value; the reference's local ray
+        // direction differs from the rotated difference by a few 1e-7 of its length.
+        const bool rx = (m.flags & MESH_APPLY_X) != 0, rz = (m.flags & MESH_APPLY_Z) != 0;
+        auto to_mesh = [&](V3 pnt) __attribute__((always_inline)) {
+            const V3 q = spin(pnt, m.pivot, false, 1.0f, 0.0f, rz, m.inv_z_cos, m.inv_z_sin);
+            return spin(q, m.pivot, rx, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
+        };
+        g = bundle_geom(to_mesh(gw.O), to_mesh(Lw), R, 8e-6f);
+        if (!g.ok) return BUNDLE_UNKNOWN;
+    }
+    const V3 lo = m.lo, hi = m.hi, O = g.O;
+    const bool ax = O.x > hi.x, bx = O.x < lo.x, ay = O.y > hi.y, by = O.y < lo.y, az = O.z > hi.z, bz = O.z < lo.z;
+    // moving away (exact): beyond the max face with T - O >= 0 for every target, or beyond the min face with <= 0
+    if ((ax & (g.nlo.x > 0.0f)) | (bx & (g.nhi.x < 0.0f)) | (ay & (g.nlo.y > 0.0f)) | (by & (g.nhi.y < 0.0f)) | (az & (g.nlo.z > 0.0f)) |
+        (bz & (g.nhi.z < 0.0f)))
+        return BUNDLE_MISS;
+    const float scale = smax(smax(1.0f, g.omax), smax(max3abs(lo), max3abs(hi)));
+    const float mg = 2e-5f * scale;  // >= 8 x the float error of a crossing point (a few ulp of box-sized numbers)
+    const int n_out = static_cast<int>(ax | bx) + static_cast<int>(ay | by) + static_cast<int>(az | bz);
+    if (n_out > 1) return BUNDLE_UNKNOWN;
+    // strictly inside the slabs of the other axes
+    const bool ix = (O.x - lo.x > mg) & (hi.x - O.x > mg), iy = (O.y - lo.y > mg) & (hi.y - O.y > mg), iz = (O.z - lo.z > mg) & (hi.z - O.z > mg);
+    int a;
+    bool inside;
+    if (n_out == 1) {
+        a = (ax | bx) ? 0 : ((ay | by) ? 1 : 2);
+        if (!((a == 0 || ix) && (a == 1 || iy) && (a == 2 || iz))) return BUNDLE_UNKNOWN;
+        // a box without thickness on this axis: both slab distances are equal and the reference's `t0 > t1` swap
+        // (:233), hence the face it reports, no longer follows the ray's direction
+        if (!(comp(hi, a) - comp(lo, a) > mg)) return BUNDLE_UNKNOWN;
+        inside = false;
+    } else {
+        if (!(ix & iy & iz)) return BUNDLE_UNKNOWN;
+        inside = true;
+        // exit axis of the central ray: the smallest fraction s = (face - O) / (L - O) over the axes whose sign is
+        // the same for every target (the rectangle test below proves it for the whole bundle, or fails)
+        float best = kFltMax;
+        a = -1;
+        auto axis = [&](int c, float o, float l, float h, float nl, float nh) __attribute__((always_inline)) {
+            if (!((nl > 0.0f) | (nh < 0.0f))) return;
+            const float d = 0.5f * (nl + nh);
+            const float s = ((d > 0.0f ? h : l) - o) * __builtin_amdgcn_rcpf(d);
+            if (s < best) {
+                best = s;
+                a = c;
+            }
+        };
+        axis(0, O.x, lo.x, hi.x, g.nlo.x, g.nhi.x);
+        axis(1, O.y, lo.y, hi.y, g.nlo.y, g.nhi.y);
+        axis(2, O.z, lo.z, hi.z, g.nlo.z, g.nhi.z);
+        if (a < 0) return BUNDLE_UNKNOWN;
+    }
+    const int b1 = a == 0 ? 1 : 0, b2 = a == 2 ? 1 : 2;
+    const float nl_a = comp(g.nlo, a), nh_a = comp(g.nhi, a);
+    const bool towards_max = nl_a > 0.0f;  // every ray's direction component on axis a is positive
+    if (!(towards_max | (nh_a < 0.0f))) return BUNDLE_UNKNOWN;
+    // outside: heading inwards on axis a (otherwise the moving-away rule has answered already)
+    if (!inside && towards_max != (a == 0 ? bx : (a == 1 ? by : bz))) return BUNDLE_UNKNOWN;
+    // the face the rays cross: inside → they leave through it; outside → they enter through it
+    const bool face_max = inside ? towards_max : !towards_max;
+    const float f_a = face_max ? comp(hi, a) : comp(lo, a);
+    const float h = f_a - comp(O, a);                     // signed like T - O on this axis
+    const float d_near = towards_max ? nl_a : nh_a;       // closest to 0
+    const float d_far = towards_max ? nh_a : nl_a;
+    if (!(__builtin_fabsf(d_near) > 1e-6f * g.dist_hi)) return BUNDLE_UNKNOWN;  // |dir_a| >= 1e-8: the axis is never "parallel" (:222)
+    // fraction of the way to the target at which a ray crosses the plane: s = h / (T_a - O_a) > 0
+    const float s_lo = h * __builtin_amdgcn_rcpf(d_far) * (1.0f - 1e-5f), s_hi = h * __builtin_amdgcn_rcpf(d_near) * (1.0f + 1e-5f);
+    if (!(s_lo >= 0.0f)) return BUNDLE_UNKNOWN;
+    const float t_hi = s_hi * g.dist_hi;  // the distance along a ray is at most this
+    const float mg2 = mg + 8e-6f * t_hi;  // the slab distances being compared carry a relative error, and so do the directions
+    if (!(t_hi + mg2 < g.dist_lo * 0.999f)) return BUNDLE_UNKNOWN;  // `hit.t < distToLight` (shading.cpp:25) holds for every ray
+    auto cross_lo = [&](float o, float nl) __attribute__((always_inline)) { return o + (nl >= 0.0f ? s_lo * nl : s_hi * nl) - mg2; };
+    auto cross_hi = [&](float o, float nh) __attribute__((always_inline)) { return o + (nh >= 0.0f ? s_hi * nh : s_lo * nh) + mg2; };
+    const float x1lo = cross_lo(comp(O, b1), comp(g.nlo, b1)), x1hi = cross_hi(comp(O, b1), comp(g.nhi, b1));
+    const float x2lo = cross_lo(comp(O, b2), comp(g.nlo, b2)), x2hi = cross_hi(comp(O, b2), comp(g.nhi, b2));
+    const float l1 = comp(lo, b1), h1 = comp(hi, b1), l2 = comp(lo, b2), h2 = comp(hi, b2);
+    const bool through = (x1lo > l1 + mg2) & (x1hi < h1 - mg2) & (x2lo > l2 + mg2) & (x2hi < h2 - mg2);
+    if (!through) {
+        // beyond one face and the crossing points lie beside the face: by then the ray has left another slab → miss
+        if (!inside && ((x1hi < l1 - mg2) | (x1lo > h1 + mg2) | (x2hi < l2 - mg2) | (x2lo > h2 + mg2))) return BUNDLE_MISS;
+        return BUNDLE_UNKNOWN;
+    }
+    // every ray reports face (a, neg) first, at a distance below its light distance
+    if (m.flags & MESH_OPAQUE) return BUNDLE_HIT;
+    const bool neg = inside ? !towards_max : towards_max;  // exit: the min side when heading down; entry: the min side when heading up
+    const int face = face_slot(a, neg);
+    int off, w, hgt;
+    if constexpr (SV::kLds) {
+        const MCRT_LDS int* f = sc.faces + (mesh_index * 6 + face) * 4;
+        off = f[0], w = f[1], hgt = f[2];
+    } else {
+        const FlatMesh& fm = sc.meshes[mesh_index];
+        off = fm.tex_off[face], w = fm.tex_w[face], hgt = fm.tex_h[face];
+    }
+    if (off < 0) return BUNDLE_HIT;  // null / empty texture: alpha 1
+    V3 c1 = O, c2 = O;  // the rectangle's corners (the coordinate on axis a does not enter the face's u,v)
+    if (a == 0) c1.y = x1lo, c2.y = x1hi, c1.z = x2lo, c2.z = x2hi;
+    if (a == 1) c1.x = x1lo, c2.x = x1hi, c1.z = x2lo, c2.z = x2hi;
+    if (a == 2) c1.x = x1lo, c2.x = x1hi, c1.y = x2lo, c2.y = x2hi;
+    float u1, v1, u2, v2;
+    face_uv(c1, lo, hi, a, neg, u1, v1);
+    face_uv(c2, lo, hi, a, neg, u2, v2);
+    const int tx1 = iclamp(static_cast<int>(u1 * w), 0, w - 1), tx2 = iclamp(static_cast<int>(u2 * w), 0, w - 1);
+    const int ty1 = iclamp(static_cast<int>(v1 * hgt), 0, hgt - 1), ty2 = iclamp(static_cast<int>(v2 * hgt), 0, hgt - 1);
+    const int txa = tx1 < tx2 ? tx1 : tx2, txb = tx1 < tx2 ? tx2 : tx1, tya = ty1 < ty2 ? ty1 : ty2, tyb = ty1 < ty2 ? ty2 : ty1;
+    if (txb - txa > 1 || tyb - tya > 1) return BUNDLE_UNKNOWN;
+    const uint32_t b00 = alpha_bits(sc, off + tya * w + txa), b01 = alpha_bits(sc, off + tya * w + txb);
+    const uint32_t b10 = alpha_bits(sc, off + tyb * w + txa), b11 = alpha_bits(sc, off + tyb * w + txb);
+    const uint32_t any_clear = (b00 | b01 | b10 | b11) & 1u, all_clear = b00 & b01 & b10 & b11 & 1u;
+    if (!any_clear) return BUNDLE_HIT;  // texColor.a != 0 for every ray (:311)
+    if (!all_clear) return BUNDLE_UNKNOWN;
+    // every ray meets a transparent texel: an exit face ends the test (tmax > tHit fails, :318), an inner-layer
+    // entry face too (:312); an outer-layer entry face goes on to the exit face
+    if (inside || !(m.flags & MESH_OUTER)) return BUNDLE_MISS;
+    return BUNDLE_UNKNOWN;
+}
+// Lit count of a hit when every candidate is decided: 0 (some mesh stops every ray), S (no mesh stops any), or -1;
+// `cand` loses the meshes that no ray can hit.
+template <class SV>
+DEV int bundle_decide(const SV& sc, V3 O, V3 L, float R, int S, unsigned long long& cand) {
+    if (sc.n_meshes > 64) return -1;  // meshes beyond the mask are tested per ray
+    const BundleGeom g = bundle_geom(O, L, R, 0.0f);
+    if (!g.ok) return -1;
+    unsigned long long rest = cand, keep = 0ull;
+    while (rest) {
+        const int i = __builtin_ctzll(rest);
+        rest &= rest - 1ull;
+        const int r = bundle_decide_mesh(sc, mesh_lane(sc, i), i, g, L, R);
+        if (r == BUNDLE_HIT) return 0;
+        if (r == BUNDLE_UNKNOWN) keep |= 1ull << i;
+    }
+    cand = keep;
+    return keep ? -1 : S;
+}
+
 // Conservative first pass for ALL ambient-occlusion rays of one hit (computeAO, raytracer.cpp:38-78):
 // they start at O and only count hits closer than `radius`, so only meshes whose box (bounding
 // sphere when posed) comes within `radius` of O can matter.

@@ -1,13 +1,16 @@
-"""Long randomised parity sweep: HIP path vs the CPU oracle, bit-exact.  usage: gpu_fuzz.py <first_seed> <count>"""
+"""Long randomised parity sweep: HIP path vs the CPU oracle, bit-exact.  usage: gpu_fuzz.py <first_seed> <count> [bundle]
+(bundle: the cases aimed at the whole-bundle shadow decisions, fuzz_cases.make_bundle_case)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import minecraftskin_raytracer_amd as M
 import oraclelib
-from fuzz_cases import make_case
+from fuzz_cases import make_bundle_case, make_case
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+if len(sys.argv) > 3 and sys.argv[3] == "bundle":
+    make_case = make_bundle_case
 orc = oraclelib.Oracle()
 bad = 0
 t0 = time.time()
