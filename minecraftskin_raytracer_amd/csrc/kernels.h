@@ -98,7 +98,8 @@ struct RenderParams {
     int rows_per_batch;    // owned tile rows per pipeline pass
     int bg_in_plan;        // 1: `plan_tiles` renders the background tiles from the draws in LDS and only touched tiles' draws
                            //    go to HBM; 0 (more than 24 draws per pixel): all streams to HBM, `primary` renders them
-    int lit_round;         // `lit`: records per round (their light samples live in LDS between its two phases)
+    int lit_round;         // `lit`: records per round (a block of 256)
+    int lit_pass;          // `lit`: traced records per pass (their light samples live in LDS between two phases)
     int lit_lds_offset;    // `lit`: byte offset of that area in dynamic LDS (behind the scene tables, 16-aligned)
     int lit_lds_bytes;     // `lit`: its size
     int flat;              // 1: flat pipeline (all levels' records shaded at once); 0: general variants, one launch set per level

@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
 #endif
 template <int kView>
 __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
-    extern __shared__ __align__(16) unsigned char s_dyn[];  // [scene tables][masks][positions: lit_round x S x 3 floats][lit counts][undecided list]
+    extern __shared__ __align__(16) unsigned char s_dyn[];  // [scene tables][masks: lit_round][positions: lit_pass x S x 3 floats][lit counts: lit_round][undecided list: lit_round]
     __shared__ int s_wcnt[kBlock / 64];
 #ifdef MCRT_DECIDE_CHECK  // verification build (tools/decide_check.sh): every decided record is traced as well
     __shared__ uint32_t s_stat[kBlock];
@@ -1025,7 +1025,8 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const uint32_t round = static_cast<uint32_t>(p.lit_round);
     unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_dyn + p.lit_lds_offset);  // 16-aligned
     float* s_pos = reinterpret_cast<float*>(s_cand + round);
-    uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + static_cast<size_t>(round) * pairs_per_hit * 3);
+    const uint32_t pass = static_cast<uint32_t>(p.lit_pass);  // records whose sample positions fit the LDS area at once
+    uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + static_cast<size_t>(pass) * pairs_per_hit * 3);
     uint32_t* s_und = s_lit + round;  // the round's undecided records, packed
     const V3 lpos = ld3(scg.hdr->light_pos);
     const float lradius = scg.hdr->light_radius;
@@ -1047,14 +1048,14 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
         for (uint32_t r0 = 0; r0 < n; r0 += round) {  // uniform
             const uint32_t m = min(round, n - r0);
             const uint32_t base = first + r0;
-            // ---- phase A1: a lane per record — the bundle mask, and whether the whole bundle is decided (rt::bundle_decide)
+            // ---- phase A1: a lane per record — the bundle mask, and whether the whole bundle is decided (rt::bundle_classify)
             bool undecided = false;
             if (threadIdx.x < m) {
                 if (mode == SHADOW_SOFT) {
                     const RecordGeom g = load_geom(ws, posed, base + threadIdx.x);
                     const V3 O = g.p + g.n * 1e-3f;
-                    unsigned long long cand = bundle_candidates<kPosed>(scg, O, lpos, lradius);
-                    const int known = p.bundle_decisions ? bundle_decide(sc, O, lpos, lradius, S, cand) : -1;
+                    unsigned long long cand;
+                    const int known = bundle_classify<kPosed>(scg, sc, O, lpos, lradius, S, p.bundle_decisions != 0, cand);
                     undecided = known < 0;
 #ifdef MCRT_DECIDE_CHECK
                     s_stat[threadIdx.x] = static_cast<uint32_t>(known + 1);
@@ -1078,9 +1079,15 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                     goto shade_round;
                 }
                 __syncthreads();
+            }
+            // the traced records in passes of up to `pass` (their sample positions share the LDS area: with the
+            // bundle decisions few records of a round are left, and the area is sized for those)
+            for (uint32_t u0 = 0; u0 < n_und; u0 += pass) {  // uniform
+                const uint32_t nu = min(pass, n_und - u0);
+                if (u0) __syncthreads();  // the previous pass's rays have read the positions
                 // ---- phase A2: a lane per undecided record — its mt19937 stream and the S disk sample positions
-                if (threadIdx.x < n_und) {
-                    const RecordGeom g = load_geom(ws, posed, base + s_und[threadIdx.x]);
+                if (mode == SHADOW_SOFT && threadIdx.x < nu) {
+                    const RecordGeom g = load_geom(ws, posed, base + s_und[u0 + threadIdx.x]);
                     const V3 P = g.p;
                     MtShort rng;
                     const uint32_t seed = shadow_seed(P, g.depth);
@@ -1100,17 +1107,15 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                         dst[3 * i + 2] = t.z;
                     }
                 }
-            }
-            __syncthreads();
-            {
+                __syncthreads();
                 // ---- phase B: a lane per (undecided record, light sample); every lane of a wave runs the same number of turns (ballot inside)
-                const uint32_t total = n_und * pairs_per_hit;
+                const uint32_t total = nu * pairs_per_hit;
                 for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) {
                     const uint32_t q = q0 + lane;
                     bool visible = false;
                     uint32_t k = 0;
                     if (q < total) {
-                        const uint32_t j = q / pairs_per_hit;
+                        const uint32_t j = u0 + q / pairs_per_hit;
                         k = (mode == SHADOW_SOFT) ? s_und[j] : j;
                         V3 P, N;
                         load_point_normal(ws, posed, base + k, P, N);
@@ -1569,9 +1574,9 @@ static bool soft_sampling(const mcrt_config& c) { return c.soft_shadows && c.sha
 // kFlatMaxBounces reflection levels (1 + maxBounces records per sample slot in the worst case).
 constexpr int kFlatMaxBounces = 8;
 #ifndef MCRT_LIT_LDS_KB
-#define MCRT_LIT_LDS_KB 32
+#define MCRT_LIT_LDS_KB 9
 #endif
-constexpr size_t kLitLdsBytes = MCRT_LIT_LDS_KB * 1024;  // `lit`: LDS for the sample positions, masks and counts of a round of records
+constexpr size_t kLitLdsBytes = MCRT_LIT_LDS_KB * 1024;  // `lit`: LDS for the sample positions of the records whose rays are traced, per pass
 // rare features that need the general kernel variants (one launch set per level, ping-pong queues): per-hit RNG
 // streams longer than the register-only engine covers (they run AO inside `level_shade`, sequentially), or
 // more bounces than the flat record arrays are laid out for
@@ -1615,14 +1620,16 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     const size_t hbm_rays = p.flat ? A : rays;
     const size_t ray_recs = p.flat ? 1 : recs;
     const size_t per_entry = 16 + 4 + recs * (5 * 16 + 4) + ray_recs * (12 * hbm_rays + (hbm_rays ? 8 : 0) + 4) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
-    // `lit`: records per round such that their sample positions, masks and counts fit its LDS budget
+    // `lit`: a round is a block of up to 256 records (masks, counts and the list of traced records in LDS); the sample
+    // positions of the records whose rays are traced go through an area of kLitLdsBytes, `lit_pass` records at a time
     {
         const size_t pairs = S ? S : 1;
-        size_t round = kLitLdsBytes / (12 * pairs + 16);
-        if (round > static_cast<size_t>(kBlock)) round = kBlock;
-        if (round < 1) round = 1;
-        p.lit_round = static_cast<int>(round);
-        p.lit_lds_bytes = static_cast<int>(round * (12 * pairs + 16));
+        size_t pass = kLitLdsBytes / (12 * pairs);
+        if (pass > static_cast<size_t>(kBlock)) pass = kBlock;
+        if (pass < 1) pass = 1;
+        p.lit_round = kBlock;
+        p.lit_pass = static_cast<int>(pass);
+        p.lit_lds_bytes = static_cast<int>(pass * 12 * pairs + static_cast<size_t>(kBlock) * 16);
         p.lit_lds_offset = static_cast<int>((scene_table_bytes(p) + 15) & ~static_cast<size_t>(15));
     }
     const int owned = p.shard.owned_rows;

@@ -950,17 +950,35 @@ DEV int bundle_decide_mesh(const SV& sc, const MeshData& m, int mesh_index, cons
         off = fm.tex_off[face], w = fm.tex_w[face], hgt = fm.tex_h[face];
     }
     if (off < 0) return BUNDLE_HIT;  // null / empty texture: alpha 1
-    V3 c1 = O, c2 = O;  // the rectangle's corners (the coordinate on axis a does not enter the face's u,v)
-    if (a == 0) c1.y = x1lo, c2.y = x1hi, c1.z = x2lo, c2.z = x2hi;
-    if (a == 1) c1.x = x1lo, c2.x = x1hi, c1.z = x2lo, c2.z = x2hi;
-    if (a == 2) c1.x = x1lo, c2.x = x1hi, c1.y = x2lo, c2.y = x2hi;
-    float u1, v1, u2, v2;
-    face_uv(c1, lo, hi, a, neg, u1, v1);
-    face_uv(c2, lo, hi, a, neg, u2, v2);
-    const int tx1 = iclamp(static_cast<int>(u1 * w), 0, w - 1), tx2 = iclamp(static_cast<int>(u2 * w), 0, w - 1);
-    const int ty1 = iclamp(static_cast<int>(v1 * hgt), 0, hgt - 1), ty2 = iclamp(static_cast<int>(v2 * hgt), 0, hgt - 1);
-    const int txa = tx1 < tx2 ? tx1 : tx2, txb = tx1 < tx2 ? tx2 : tx1, tya = ty1 < ty2 ? ty1 : ty2, tyb = ty1 < ty2 ? ty2 : ty1;
-    if (txb - txa > 1 || tyb - tya > 1) return BUNDLE_UNKNOWN;
+    // The texels under the rectangle.  The reference maps a crossing point to a texel by float u,v (computeFaceUV
+    // :136-196, TextureRegion::sample): per coordinate a monotone function of the point.  Here the same map in plain
+    // arithmetic with a margin of 1e-3 texel (+ the maps' own float error, which grows with the texel count): the
+    // reference's texel of every ray lies between the two ends.
+    //   axis z: u ← x (mirrored on the min side), v ← y mirrored;  axis x: u ← z (mirrored on the max side),
+    //   v ← y mirrored;  axis y: u ← x, v ← z (mirrored on the min side)
+    const bool u_from_b2 = a == 0;
+    const float ul = u_from_b2 ? x2lo : x1lo, uh = u_from_b2 ? x2hi : x1hi, ulo = u_from_b2 ? l2 : l1, uhi = u_from_b2 ? h2 : h1;
+    const float vl = u_from_b2 ? x1lo : x2lo, vh = u_from_b2 ? x1hi : x2hi, vlo = u_from_b2 ? l1 : l2, vhi = u_from_b2 ? h1 : h2;
+    const bool u_flip = a == 2 ? neg : (a == 0 ? !neg : false), v_flip = a == 1 ? neg : true;
+    const float iu = __builtin_amdgcn_rcpf(uhi - ulo), iv = __builtin_amdgcn_rcpf(vhi - vlo);  // extents > 2 mg (strictly inside, above)
+    float u0 = (ul - ulo) * iu, u1 = (uh - ulo) * iu, v0 = (vl - vlo) * iv, v1 = (vh - vlo) * iv;
+    if (u_flip) {
+        const float t = 1.0f - u1;
+        u1 = 1.0f - u0;
+        u0 = t;
+    }
+    if (v_flip) {
+        const float t = 1.0f - v1;
+        v1 = 1.0f - v0;
+        v0 = t;
+    }
+    const float fw = static_cast<float>(w), fh = static_cast<float>(hgt);
+    const float du = 1e-3f + 4e-6f * fw, dv = 1e-3f + 4e-6f * fh;
+    const int txa = iclamp(static_cast<int>(__builtin_floorf(sclamp(u0, 0.0f, 1.0f) * fw - du)), 0, w - 1);
+    const int txb = iclamp(static_cast<int>(__builtin_floorf(sclamp(u1, 0.0f, 1.0f) * fw + du)), 0, w - 1);
+    const int tya = iclamp(static_cast<int>(__builtin_floorf(sclamp(v0, 0.0f, 1.0f) * fh - dv)), 0, hgt - 1);
+    const int tyb = iclamp(static_cast<int>(__builtin_floorf(sclamp(v1, 0.0f, 1.0f) * fh + dv)), 0, hgt - 1);
+    if (!(txb - txa <= 1 && tyb - tya <= 1 && txb >= txa && tyb >= tya)) return BUNDLE_UNKNOWN;  // also NaN bounds
     const uint32_t b00 = alpha_bits(sc, off + tya * w + txa), b01 = alpha_bits(sc, off + tya * w + txb);
     const uint32_t b10 = alpha_bits(sc, off + tyb * w + txa), b11 = alpha_bits(sc, off + tyb * w + txb);
     const uint32_t any_clear = (b00 | b01 | b10 | b11) & 1u, all_clear = b00 & b01 & b10 & b11 & 1u;
@@ -971,23 +989,80 @@ DEV int bundle_decide_mesh(const SV& sc, const MeshData& m, int mesh_index, cons
     if (inside || !(m.flags & MESH_OUTER)) return BUNDLE_MISS;
     return BUNDLE_UNKNOWN;
 }
-// Lit count of a hit when every candidate is decided: 0 (some mesh stops every ray), S (no mesh stops any), or -1;
-// `cand` loses the meshes that no ray can hit.
-template <class SV>
-DEV int bundle_decide(const SV& sc, V3 O, V3 L, float R, int S, unsigned long long& cand) {
-    if (sc.n_meshes > 64) return -1;  // meshes beyond the mask are tested per ray
+// Candidates and decisions of one hit in ONE wave-uniform loop over the group roots (scalar mesh data): the exact
+// moving-away rule and bundle_candidates' conservative segment test on the root's box — both hold for the members
+// inside it — then, for the groups some lane of the wave still needs, bundle_decide_mesh per member.
+// Returns the hit's lit count when every candidate is decided — 0 (some mesh stops every ray) or S (no mesh stops
+// any) — else -1; `cand` = the meshes whose rays have to be traced.  decide = false: candidates only.
+template <bool kPosed, class SV>
+DEV int bundle_classify(const SceneView& scg, const SV& sc, V3 O, V3 L, float R, int S, bool decide, unsigned long long& cand) {
     const BundleGeom g = bundle_geom(O, L, R, 0.0f);
-    if (!g.ok) return -1;
-    unsigned long long rest = cand, keep = 0ull;
-    while (rest) {
-        const int i = __builtin_ctzll(rest);
-        rest &= rest - 1ull;
-        const int r = bundle_decide_mesh(sc, mesh_lane(sc, i), i, g, L, R);
-        if (r == BUNDLE_HIT) return 0;
-        if (r == BUNDLE_UNKNOWN) keep |= 1ull << i;
+    decide = decide && g.ok && scg.n_meshes <= 64;  // meshes beyond the mask are tested per ray
+    const V3 D = L - O;
+    const float Rb = R * 1.001f + 1e-6f;
+    const float slack = 2e-3f;
+    unsigned long long keep = 0ull;
+    bool dark = false;
+    const int n = scg.n_meshes < 64 ? scg.n_meshes : 64;
+    const unsigned long long roots = scg.roots;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        if (!((roots >> i) & 1ull)) continue;
+        const MeshData m = mesh_uniform(scg, i);
+        if (m.flags & MESH_EMPTY) continue;
+        const bool rotated = kPosed && (m.flags & MESH_ROTATED) != 0;
+        bool pass = true;
+        V3 o = O, d = D;
+        if (rotated) {
+            const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
+            auto to_mesh = [&](V3 pnt) __attribute__((always_inline)) {
+                V3 q = spin(pnt, m.pivot, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
+                return spin(q, m.pivot, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
+            };
+            o = to_mesh(O);
+            d = to_mesh(L) - o;
+        } else if (decide) {
+            // moving away from the root's box (exact, see bundle_decide_mesh): its members lie inside it
+            pass = !(((O.x > m.hi.x) & (g.nlo.x > 0.0f)) | ((O.x < m.lo.x) & (g.nhi.x < 0.0f)) | ((O.y > m.hi.y) & (g.nlo.y > 0.0f)) |
+                     ((O.y < m.lo.y) & (g.nhi.y < 0.0f)) | ((O.z > m.hi.z) & (g.nlo.z > 0.0f)) | ((O.z < m.lo.z) & (g.nhi.z < 0.0f)));
+            if (!__ballot(pass)) continue;
+        }
+        {   // bundle_candidates' segment test
+            float s_in = -1e-4f, s_out = 1.0f + 1e-4f;
+            bool ok = true;
+            auto axis = [&](float o1, float d1, float l, float h) __attribute__((always_inline)) {
+                const float al = d1 + Rb, bl = l - slack - o1;  // al·s >= bl
+                const float ah = d1 - Rb, bh = h + slack - o1;  // ah·s <= bh
+                const float ql = bl * __builtin_amdgcn_rcpf(al), qh = bh * __builtin_amdgcn_rcpf(ah);
+                const bool flat_l = __builtin_fabsf(al) < 1e-6f, flat_h = __builtin_fabsf(ah) < 1e-6f;
+                ok = ok & !(flat_l & (bl > 1e-5f)) & !(flat_h & (bh < -1e-5f));
+                s_in = (!flat_l & (al > 0.0f)) ? smax(s_in, ql - 1e-5f) : s_in;
+                s_out = (!flat_l & (al < 0.0f)) ? smin(s_out, ql + 1e-5f) : s_out;
+                s_out = (!flat_h & (ah > 0.0f)) ? smin(s_out, qh + 1e-5f) : s_out;
+                s_in = (!flat_h & (ah < 0.0f)) ? smax(s_in, qh - 1e-5f) : s_in;
+            };
+            axis(o.x, d.x, m.lo.x, m.hi.x);
+            axis(o.y, d.y, m.lo.y, m.hi.y);
+            axis(o.z, d.z, m.lo.z, m.hi.z);
+            pass = pass & ok & !(s_in > s_out);
+        }
+        if (!__ballot(pass)) continue;
+        if (!decide) {
+            if (pass) keep |= m.group;
+            continue;
+        }
+        unsigned long long grp = m.group;  // uniform
+        while (grp) {
+            const int j = __builtin_ctzll(grp);
+            grp &= grp - 1ull;
+            const int r = bundle_decide_mesh(sc, mesh_uniform(scg, j), j, g, L, R);
+            dark = dark | (pass & (r == BUNDLE_HIT));
+            if (pass & (r == BUNDLE_UNKNOWN)) keep |= 1ull << j;
+        }
     }
     cand = keep;
-    return keep ? -1 : S;
+    if (!decide) return -1;
+    return dark ? 0 : (keep ? -1 : S);
 }
 
 // Conservative first pass for ALL ambient-occlusion rays of one hit (computeAO, raytracer.cpp:38-78):
