@@ -994,13 +994,50 @@ DEV int bundle_decide_mesh(const SV& sc, const MeshData& m, int mesh_index, cons
 // inside it — then, for the groups some lane of the wave still needs, bundle_decide_mesh per member.
 // Returns the hit's lit count when every candidate is decided — 0 (some mesh stops every ray) or S (no mesh stops
 // any) — else -1; `cand` = the meshes whose rays have to be traced.  decide = false: candidates only.
+// bundle_candidates' segment test with the ray-dependent half prepared once per hit: along one axis the box inflated
+// by s·Rb holds the segment point o + s·d iff (d + Rb)·s >= lo - slack - o and (d - Rb)·s <= hi + slack - o, i.e. each
+// side bounds s from below or from above depending on the sign of its coefficient.  Every half-constraint becomes a
+// pair (c, k) with bound = fma(b, c, k): c = 1/coefficient and k = -+1e-5 where it applies, c = 0 and k = -+1e30
+// where it does not.  Plain floats, no per-lane booleans: the loop over the roots keeps them in VGPRs (as booleans
+// they were lane masks in SGPR pairs, hoisted out of the loop and spilled: two v_readlane per use).
+struct SegAxis {
+    float c_in_lo, k_in_lo, c_out_lo, k_out_lo;  // from the min face
+    float c_in_hi, k_in_hi, c_out_hi, k_out_hi;  // from the max face
+};
+DEV SegAxis seg_axis(float d1, float Rb) {
+    float al = d1 + Rb, ah = d1 - Rb;
+    // a vanishing coefficient (a constraint that does not depend on s) is nudged to 1e-6: far inside the test's slack
+    al = __builtin_fabsf(al) < 1e-6f ? 1e-6f : al;
+    ah = __builtin_fabsf(ah) < 1e-6f ? 1e-6f : ah;
+    const float ial = __builtin_amdgcn_rcpf(al), iah = __builtin_amdgcn_rcpf(ah);
+    const float big = 1e30f, eps = 1e-5f;
+    SegAxis c;
+    c.c_in_lo = al > 0.0f ? ial : 0.0f, c.k_in_lo = al > 0.0f ? -eps : -big;  // al·s >= bl, al > 0: s >= bl / al
+    c.c_out_lo = al > 0.0f ? 0.0f : ial, c.k_out_lo = al > 0.0f ? big : eps;  //              al < 0: s <= bl / al
+    c.c_out_hi = ah > 0.0f ? iah : 0.0f, c.k_out_hi = ah > 0.0f ? eps : big;  // ah·s <= bh, ah > 0: s <= bh / ah
+    c.c_in_hi = ah > 0.0f ? 0.0f : iah, c.k_in_hi = ah > 0.0f ? -big : -eps;  //              ah < 0: s >= bh / ah
+    return c;
+}
+DEV void seg_axis_apply(const SegAxis& c, float o1, float l, float h, float& s_in, float& s_out) {
+    const float slack = 2e-3f;
+    const float bl = (l - o1) - slack, bh = (h - o1) + slack;
+    s_in = __builtin_fmaxf(s_in, __builtin_fmaxf(__builtin_fmaf(bl, c.c_in_lo, c.k_in_lo), __builtin_fmaf(bh, c.c_in_hi, c.k_in_hi)));
+    s_out = __builtin_fminf(s_out, __builtin_fminf(__builtin_fmaf(bl, c.c_out_lo, c.k_out_lo), __builtin_fmaf(bh, c.c_out_hi, c.k_out_hi)));
+}
+
 template <bool kPosed, class SV>
 DEV int bundle_classify(const SceneView& scg, const SV& sc, V3 O, V3 L, float R, int S, bool decide, unsigned long long& cand) {
     const BundleGeom g = bundle_geom(O, L, R, 0.0f);
     decide = decide && g.ok && scg.n_meshes <= 64;  // meshes beyond the mask are tested per ray
     const V3 D = L - O;
     const float Rb = R * 1.001f + 1e-6f;
-    const float slack = 2e-3f;
+    const SegAxis cx = seg_axis(D.x, Rb), cy = seg_axis(D.y, Rb), cz = seg_axis(D.z, Rb);
+    // moving away from a box (exact, see bundle_decide_mesh), as floats: up = -1 where every target lies above the
+    // origin on that axis, dn = 1 where below; the rule holds iff up·(hi - O) > 0 or dn·(lo - O) > 0 (float
+    // subtraction keeps the sign of the comparison)
+    const float upx = (decide & (g.nlo.x > 0.0f)) ? -1.0f : 0.0f, dnx = (decide & (g.nhi.x < 0.0f)) ? 1.0f : 0.0f;
+    const float upy = (decide & (g.nlo.y > 0.0f)) ? -1.0f : 0.0f, dny = (decide & (g.nhi.y < 0.0f)) ? 1.0f : 0.0f;
+    const float upz = (decide & (g.nlo.z > 0.0f)) ? -1.0f : 0.0f, dnz = (decide & (g.nhi.z < 0.0f)) ? 1.0f : 0.0f;
     unsigned long long keep = 0ull;
     bool dark = false;
     const int n = scg.n_meshes < 64 ? scg.n_meshes : 64;
@@ -1011,41 +1048,27 @@ DEV int bundle_classify(const SceneView& scg, const SV& sc, V3 O, V3 L, float R,
         const MeshData m = mesh_uniform(scg, i);
         if (m.flags & MESH_EMPTY) continue;
         const bool rotated = kPosed && (m.flags & MESH_ROTATED) != 0;
-        bool pass = true;
-        V3 o = O, d = D;
-        if (rotated) {
+        float s_in = -1e-4f, s_out = 1.0f + 1e-4f, away = 0.0f;
+        if (rotated) {  // the segment in the mesh's frame
             const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
             auto to_mesh = [&](V3 pnt) __attribute__((always_inline)) {
                 V3 q = spin(pnt, m.pivot, false, 1.0f, 0.0f, az, m.inv_z_cos, m.inv_z_sin);
                 return spin(q, m.pivot, ax, m.inv_x_cos, m.inv_x_sin, false, 1.0f, 0.0f);
             };
-            o = to_mesh(O);
-            d = to_mesh(L) - o;
-        } else if (decide) {
-            // moving away from the root's box (exact, see bundle_decide_mesh): its members lie inside it
-            pass = !(((O.x > m.hi.x) & (g.nlo.x > 0.0f)) | ((O.x < m.lo.x) & (g.nhi.x < 0.0f)) | ((O.y > m.hi.y) & (g.nlo.y > 0.0f)) |
-                     ((O.y < m.lo.y) & (g.nhi.y < 0.0f)) | ((O.z > m.hi.z) & (g.nlo.z > 0.0f)) | ((O.z < m.lo.z) & (g.nhi.z < 0.0f)));
-            if (!__ballot(pass)) continue;
+            const V3 o = to_mesh(O);
+            const V3 d = to_mesh(L) - o;
+            seg_axis_apply(seg_axis(d.x, Rb), o.x, m.lo.x, m.hi.x, s_in, s_out);
+            seg_axis_apply(seg_axis(d.y, Rb), o.y, m.lo.y, m.hi.y, s_in, s_out);
+            seg_axis_apply(seg_axis(d.z, Rb), o.z, m.lo.z, m.hi.z, s_in, s_out);
+        } else {  // its members lie inside the root's box: moving away from it is moving away from them
+            away = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(upx * (m.hi.x - O.x), dnx * (m.lo.x - O.x)),
+                                                   __builtin_fmaxf(upy * (m.hi.y - O.y), dny * (m.lo.y - O.y))),
+                                   __builtin_fmaxf(upz * (m.hi.z - O.z), dnz * (m.lo.z - O.z)));
+            seg_axis_apply(cx, O.x, m.lo.x, m.hi.x, s_in, s_out);
+            seg_axis_apply(cy, O.y, m.lo.y, m.hi.y, s_in, s_out);
+            seg_axis_apply(cz, O.z, m.lo.z, m.hi.z, s_in, s_out);
         }
-        {   // bundle_candidates' segment test
-            float s_in = -1e-4f, s_out = 1.0f + 1e-4f;
-            bool ok = true;
-            auto axis = [&](float o1, float d1, float l, float h) __attribute__((always_inline)) {
-                const float al = d1 + Rb, bl = l - slack - o1;  // al·s >= bl
-                const float ah = d1 - Rb, bh = h + slack - o1;  // ah·s <= bh
-                const float ql = bl * __builtin_amdgcn_rcpf(al), qh = bh * __builtin_amdgcn_rcpf(ah);
-                const bool flat_l = __builtin_fabsf(al) < 1e-6f, flat_h = __builtin_fabsf(ah) < 1e-6f;
-                ok = ok & !(flat_l & (bl > 1e-5f)) & !(flat_h & (bh < -1e-5f));
-                s_in = (!flat_l & (al > 0.0f)) ? smax(s_in, ql - 1e-5f) : s_in;
-                s_out = (!flat_l & (al < 0.0f)) ? smin(s_out, ql + 1e-5f) : s_out;
-                s_out = (!flat_h & (ah > 0.0f)) ? smin(s_out, qh + 1e-5f) : s_out;
-                s_in = (!flat_h & (ah < 0.0f)) ? smax(s_in, qh - 1e-5f) : s_in;
-            };
-            axis(o.x, d.x, m.lo.x, m.hi.x);
-            axis(o.y, d.y, m.lo.y, m.hi.y);
-            axis(o.z, d.z, m.lo.z, m.hi.z);
-            pass = pass & ok & !(s_in > s_out);
-        }
+        const bool pass = !(away > 0.0f) & !(s_in > s_out);
         if (!__ballot(pass)) continue;
         if (!decide) {
             if (pass) keep |= m.group;
