@@ -22,7 +22,8 @@
 //   chase           1 lane / level-1 record        the rest of the chain: reflect, closest hit, append, until the ray
 //                                     misses or maxBounces is reached (~10 % go on per level)
 //   ... then ONCE over the records of ALL levels (550 k + 55 k + 5 k + ... at 1080p / 4 spp):
-//   ao_dirs, ao     (AO on, primary hits)  hemisphere directions + ball mask per hit; any hit within the radius
+//   ao              (AO on) 1 lane / primary hit   the meshes its hemisphere of rays can meet; mt19937(ao seed), the A
+//                                     cosine-weighted directions and their any-hit tests within the radius, in registers
 //   lit             three phases per block of 256 records, handed over through LDS:
 //                   1 lane / record   register-only truncated mt19937 → 2·S draws → the S disk sample
 //                                     positions, and the hit's bundle mask (meshes its shadow rays can meet)
@@ -1178,87 +1179,78 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     }
 }
 
-// ambient occlusion (raytracer.cpp:38-78, depth 0 only) as two stages over the primary hits:
-// ao_dirs — lane per hit: tangent frame, mt19937(ao seed), the A cosine-weighted directions, stored
-// where the (now consumed) light samples of the primary hits were; ao — lane per (hit, direction): any hit
-// closer than the radius, counted per hit into lit[1].
-template <bool kPosed>
-__global__ __launch_bounds__(kBlock) void ao_dirs_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
-    const SceneView sc = view_of(scene_blob);
-    const WaveSpace& ws = p.ws;
-    const int A = p.cfg.ao_samples;
-    for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
-        if (threadIdx.x >= n) return;
-        const uint32_t e = first + threadIdx.x;
-        V3 P, Nraw;
-        load_point_normal(ws, p.scene_posed != 0, e, P, Nraw);
-        const V3 N = normalize(Nraw);
-        const V3 T = (__builtin_fabsf(N.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), N)) : normalize(cross(mk(0, 1, 0), N));
-        const V3 B = cross(N, T);
-        // the meshes any of this hit's AO rays can meet (the primary hits' shadow masks are consumed by now)
-        ws.cand[e] = ball_candidates<kPosed>(sc, P + N * 1e-3f, p.cfg.ao_radius);
-        MtShort rng;
-        rng.seed(ao_seed(P));
-        float* dst = ws.targets + static_cast<size_t>(e) * 3 * A;
-        for (int i = 0; i < A; ++i) {
-            const float r1 = rng.uniform();
-            const float r2 = rng.uniform();
-            const float sinT = __builtin_sqrtf(1.0f - r1);
-            const float cosT = __builtin_sqrtf(r1);
-            float sn, cs;
-            mcrt_sincosf(kTwoPi * r2, &sn, &cs);
-            const V3 local = mk(sinT * cs, cosT, sinT * sn);
-            const V3 world = normalize(T * local.x + N * local.y + B * local.z);
-            dst[3 * i + 0] = world.x;
-            dst[3 * i + 1] = world.y;
-            dst[3 * i + 2] = world.z;
-        }
-    });
-}
-
+// ambient occlusion (raytracer.cpp:38-78, depth 0 only) as one stage over the primary hits, a lane per hit:
+//   1. the meshes any of its rays can meet: within the radius (rt::ball_candidates) and not behind the hit's own
+//      face (the rays leave into the hemisphere around the normal; for an axis-aligned normal the tangent frame
+//      is made of exact axis vectors, so the component of every direction along the normal is >= 0 and a box that
+//      ends before the origin on that axis is missed by the moving-away argument of rt::bundle_decide_mesh);
+//   2. hits with no such mesh are done (0 occluded) — the others are packed onto the block's first lanes;
+//   3. per packed lane: mt19937(ao seed), and for each of the A directions the two draws, the cosine-weighted
+//      direction and the any-hit test, counted in a register.
+// (As two kernels — directions to HBM a lane per hit, rays a lane per (hit, direction) — the stage moved
+// 2 x 192 B per hit through HBM with 64 cache lines per store instruction, and every ray lane reloaded and
+// re-normalised its hit: 5.7 ms of the reference GUI's default frame; see DESIGN.md.)
+#ifndef MCRT_AO_WAVES
+#define MCRT_AO_WAVES 4
+#endif
 template <int kView>
-__global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void ao_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+__global__ __launch_bounds__(kBlock, MCRT_AO_WAVES) void ao_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
+    __shared__ int s_wcnt[kBlock / 64];
+    __shared__ uint32_t s_list[kBlock];
+    __shared__ unsigned long long s_mask[kBlock];
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
     if (blockIdx.x >= ws.counters[kCntUnits]) return;
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
-    const uint32_t A = static_cast<uint32_t>(p.cfg.ao_samples);
+    constexpr bool kPosed = kView != kViewLdsUnposed;
+    const bool posed = kPosed && p.scene_posed != 0;
+    const int A = p.cfg.ao_samples;
     const float radius = p.cfg.ao_radius;
-    const bool pow2 = (A & (A - 1u)) == 0u && A <= 64u;
-    const uint32_t lane = threadIdx.x & 63u;
     uint32_t* occ_out = ws.lit[1];
     for_each_unit_block(ws, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
-        if (!pow2) {
-            if (threadIdx.x < n) occ_out[first + threadIdx.x] = 0u;
-            __syncthreads();
+        bool traced = false;
+        if (threadIdx.x < n) {
+            const uint32_t e = first + threadIdx.x;
+            V3 P, Nraw;
+            load_point_normal(ws, posed, e, P, Nraw);
+            const V3 N = normalize(Nraw);
+            const unsigned long long cand = hemisphere_candidates<kPosed>(scg, P + N * 1e-3f, N, radius);
+            s_mask[threadIdx.x] = cand;
+            traced = cand != 0ull || scg.n_meshes > 64;  // meshes beyond the mask are tested per ray
+            if (!traced) occ_out[e] = 0u;
         }
-        const uint32_t total = n * A;
-        for (uint32_t q0 = threadIdx.x & ~63u; q0 < total; q0 += kBlock) {  // uniform trip count per wave
-            const uint32_t q = q0 + lane;
-            bool occluded = false;
-            uint32_t e = 0;
-            if (q < total) {
-                const uint32_t k = q / A;
-                const uint32_t j = q - k * A;
-                e = first + k;
-                V3 P, Nraw;
-                load_point_normal(ws, p.scene_posed != 0, e, P, Nraw);
-                const V3 N = normalize(Nraw);
-                const V3 dir = ld3(ws.targets + (static_cast<size_t>(e) * A + j) * 3);
-                const Ray r{P + N * 1e-3f, dir};
-                occluded = any_hit_masked(sc, r, radius, ws.cand[e]);
+        int total = 0;
+        const int rank = block_rank(traced, s_wcnt, total);
+        if (traced) s_list[rank] = threadIdx.x;
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < total) {
+            const uint32_t k = s_list[threadIdx.x];
+            const uint32_t e = first + k;
+            V3 P, Nraw;
+            load_point_normal(ws, posed, e, P, Nraw);
+            const V3 N = normalize(Nraw);
+            const V3 T = (__builtin_fabsf(N.x) < 0.9f) ? normalize(cross(mk(1, 0, 0), N)) : normalize(cross(mk(0, 1, 0), N));
+            const V3 B = cross(N, T);
+            const unsigned long long cand = s_mask[k];
+            const V3 O = P + N * 1e-3f;
+            MtShort rng;
+            rng.seed(ao_seed(P));
+            uint32_t occluded = 0;
+            for (int i = 0; i < A; ++i) {
+                const float r1 = rng.uniform();
+                const float r2 = rng.uniform();
+                const float sinT = __builtin_sqrtf(1.0f - r1);
+                const float cosT = __builtin_sqrtf(r1);
+                float sn, cs;
+                mcrt_sincosf(kTwoPi * r2, &sn, &cs);
+                const V3 local = mk(sinT * cs, cosT, sinT * sn);
+                const V3 world = normalize(T * local.x + N * local.y + B * local.z);
+                if (any_hit_masked(sc, Ray{O, world}, radius, cand)) ++occluded;
             }
-            if (pow2) {
-                const unsigned long long m = __ballot(occluded);
-                if (q < total && (lane & (A - 1u)) == 0u) {
-                    const unsigned long long grp = (A == 64u) ? m : ((m >> lane) & ((1ull << A) - 1ull));
-                    occ_out[e] = static_cast<uint32_t>(__popcll(grp));
-                }
-            } else if (occluded) {
-                atomicAdd(&occ_out[e], 1u);
-            }
+            occ_out[e] = occluded;
         }
+        __syncthreads();  // s_list, s_mask are reused by the next block of hits
     });
 }
 
@@ -1617,7 +1609,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     // bytes per slot: colour + end code, per record 5 float4 + light samples + mask + lit, AO counts, stack
     // light sample positions and bundle masks in HBM: general variants (per record) and the AO directions of
     // the primary hits; the flat pipeline's `lit` keeps the light samples in LDS
-    const size_t hbm_rays = p.flat ? A : rays;
+    const size_t hbm_rays = p.flat ? 0 : rays;  // the flat pipeline keeps light samples in LDS and AO directions in registers
     const size_t ray_recs = p.flat ? 1 : recs;
     const size_t per_entry = 16 + 4 + recs * (5 * 16 + 4) + ray_recs * (12 * hbm_rays + (hbm_rays ? 8 : 0) + 4) + 4 + 16 * static_cast<size_t>(p.ws.stack_stride);
     // `lit`: a round is a block of up to 256 records (masks, counts and the list of traced records in LDS); the sample
@@ -1726,7 +1718,6 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
     if (levels >= 2)  // the chains below the level-1 records `primary` found (maxBounces = 0: it has marked the chains already)
         hipLaunchKernelGGL(chase_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
-        hipLaunchKernelGGL(ao_dirs_kernel<posed>, dim3(grid), dim3(kBlock), 0, stream, p.scene, p);
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
     hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);

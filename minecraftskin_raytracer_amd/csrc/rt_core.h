@@ -1119,6 +1119,59 @@ DEV unsigned long long ball_candidates(const SV& sc, V3 O, float radius) {
     return cand;
 }
 
+// ball_candidates for the rays of computeAO, which leave into the hemisphere around the hit's normal N (unit length):
+// direction = normalize(T·x + N·y + B·z) with y = sqrt(r1) >= 0 (raytracer.cpp:44-68).  When N is an axis vector
+// ±e_a (every hit on an un-posed mesh), T and B come out of the cross products as exact axis vectors, so the
+// direction's component along a is y / |.| with N's sign: never towards the other side.  An un-posed box that ends
+// before the origin on that side — O_a > hi_a for N = +e_a, O_a < lo_a for N = -e_a — then has both slab distances of
+// axis a negative (or the axis is "parallel" with the origin outside): no AO ray of this hit can report it
+// (intersection.cpp:222-249), whatever its direction.  Exact; posed meshes and other normals are left alone.
+template <bool kPosed, class SV>
+DEV unsigned long long hemisphere_candidates(const SV& sc, V3 O, V3 N, float radius) {
+    const float reach = radius * 1.001f + 2e-3f;
+    // the normal as an axis: n_c = ±1 on one axis and ±0 on the others, else no pruning (all limits stay open)
+    const bool axial = (__builtin_fabsf(N.x) == 1.0f & N.y == 0.0f & N.z == 0.0f) | (N.x == 0.0f & __builtin_fabsf(N.y) == 1.0f & N.z == 0.0f) |
+                       (N.x == 0.0f & N.y == 0.0f & __builtin_fabsf(N.z) == 1.0f);
+    // pruned iff up_c·(O_c - hi_c) > 0 or dn_c·(lo_c - O_c) > 0 for some axis (float subtraction keeps the comparison's sign)
+    const float upx = (axial & (N.x > 0.0f)) ? 1.0f : 0.0f, dnx = (axial & (N.x < 0.0f)) ? 1.0f : 0.0f;
+    const float upy = (axial & (N.y > 0.0f)) ? 1.0f : 0.0f, dny = (axial & (N.y < 0.0f)) ? 1.0f : 0.0f;
+    const float upz = (axial & (N.z > 0.0f)) ? 1.0f : 0.0f, dnz = (axial & (N.z < 0.0f)) ? 1.0f : 0.0f;
+    unsigned long long cand = 0ull;
+    const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
+    const unsigned long long roots = sc.roots;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        if (!((roots >> i) & 1ull)) continue;
+        const MeshData m = mesh_uniform(sc, i);
+        if (m.flags & MESH_EMPTY) continue;
+        bool pass;
+        if (kPosed && (m.flags & MESH_ROTATED)) {
+            const V3 oc = m.centre - O;
+            const float rr = m.radius + reach;
+            pass = (m.radius < 0.0f) | !(dot(oc, oc) > rr * rr * 1.001f);
+            if (pass) cand |= m.group;
+            continue;
+        }
+        const float dx = smax(smax(m.lo.x - O.x, O.x - m.hi.x), 0.0f);
+        const float dy = smax(smax(m.lo.y - O.y, O.y - m.hi.y), 0.0f);
+        const float dz = smax(smax(m.lo.z - O.z, O.z - m.hi.z), 0.0f);
+        pass = !(dx * dx + dy * dy + dz * dz > reach * reach * 1.001f);
+        if (!__ballot(pass)) continue;
+        unsigned long long grp = m.group;  // uniform; the members are un-posed boxes inside the root's
+        while (grp) {
+            const int j = __builtin_ctzll(grp);
+            grp &= grp - 1ull;
+            const FlatMesh& fm = sc.meshes[j];
+            const bool rotated = kPosed && (fm.flags & MESH_ROTATED) != 0;  // (a posed mesh is its own root)
+            const float behind = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(upx * (O.x - fm.hi[0]), dnx * (fm.lo[0] - O.x)),
+                                                                 __builtin_fmaxf(upy * (O.y - fm.hi[1]), dny * (fm.lo[1] - O.y))),
+                                                 __builtin_fmaxf(upz * (O.z - fm.hi[2]), dnz * (fm.lo[2] - O.z)));
+            if (pass & (rotated | !(behind > 0.0f))) cand |= 1ull << j;
+        }
+    }
+    return cand;
+}
+
 // shared copy for the rare sequential paths (AO, very long shadow streams, probes)
 DEVCALL bool any_hit_call(SceneView sc, Ray r, float limit) { return any_hit_inline(sc, r, limit); }
 template <class SV>
