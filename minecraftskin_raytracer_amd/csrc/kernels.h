@@ -125,7 +125,7 @@ constexpr int kCounterWords = 4096;
 // tile size and the shard only — the caller keeps the result across renders and calls this when those change.
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream);
 // enqueue the whole pipeline of one lane on `stream` (p.tile_rng already seeded): per batch of tile rows
-// plan → primary (+ the primary hits' reflection rays) → chase → (ao_dirs → ao →) lit → resolve
+// plan → primary (+ the primary hits' reflection rays) → chase → (ao →) lit → resolve
 // Optional events for a caller that downloads tile rows as they become final (the one-shot host path):
 //  after_plan    recorded behind the first pass's plan_tiles: with bg_in_plan every tile row that holds no touched
 //                tile is complete then

@@ -21,13 +21,15 @@
 //                                     level-1 record; chains that end are marked
 //   chase           1 lane / level-1 record        the rest of the chain: reflect, closest hit, append, until the ray
 //                                     misses or maxBounces is reached (~10 % go on per level)
-//   ... then ONCE over the records of ALL levels (550 k + 55 k + 5 k + ... at 1080p / 4 spp):
+//   ... then ONCE over the records of ALL levels (320 k + 31 k + 3 k + ... at 1080p / 4 spp):
 //   ao              (AO on) 1 lane / primary hit   the meshes its hemisphere of rays can meet; mt19937(ao seed), the A
 //                                     cosine-weighted directions and their any-hit tests within the radius, in registers
-//   lit             three phases per block of 256 records, handed over through LDS:
-//                   1 lane / record   register-only truncated mt19937 → 2·S draws → the S disk sample
-//                                     positions, and the hit's bundle mask (meshes its shadow rays can meet)
-//                   1 lane / (record, light sample)   exact any-hit test on the bundle mask → lit count
+//   lit             phases per block of 256 records, handed over through LDS:
+//                   1 lane / record   the hit's bundle mask (meshes its shadow rays can meet) and the whole-bundle
+//                                     decision (rt::bundle_classify): most hits are provably lit by all S light
+//                                     samples or by none and need no samples and no rays; the rest are packed
+//                   1 lane / undecided record   register-only truncated mt19937 → 2·S draws → the S disk sample positions
+//                   1 lane / (undecided record, light sample)   exact any-hit test on the meshes left open → lit count
 //                   1 lane / record   Blinn-Phong (+AO) → the chain's stack of level colours
 //   resolve         1 lane / pixel    folds each sample's chain back to front, ordered sum of the pixel's sample
 //                                     colours (float addition order is part of the result), coalesced float4 / RGBA8 store
@@ -54,6 +56,15 @@ constexpr int kChunk = 256;        // work items per chunk: one per thread
 #endif
 constexpr int kPrimaryGrid = MCRT_PRIMARY_GRID; // persistent primary workgroups (4 per CU)
 constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
+
+// n / d for a divisor that is the same for the whole wave: a shift when it is a power of two (tile widths of 32,
+// 4 samples per pixel: the usual case) instead of the ~25-instruction expansion of a 32-bit division.
+struct UDiv {
+    unsigned d;
+    int shift;  // log2(d), or -1
+    __device__ __forceinline__ explicit UDiv(unsigned dv) : d(dv), shift((dv & (dv - 1u)) == 0u && dv != 0u ? static_cast<int>(__builtin_ctz(dv)) : -1) {}
+    __device__ __forceinline__ unsigned div(unsigned n) const { return shift >= 0 ? n >> shift : n / d; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // tile geometry helpers (TileRenderer::generateTiles, tile_renderer.cpp:18-39)
@@ -139,8 +150,9 @@ __device__ __forceinline__ void background_pixels(const SceneView& sc, const Ren
     const unsigned dd = static_cast<unsigned>(p.draws_per_sample);
     const float fW = static_cast<float>(cfg.width), fH = static_cast<float>(cfg.height);
     const float inv_spp = 1.0f / static_cast<float>(spp);
+    const UDiv by_w(static_cast<unsigned>(tg.w));
     for (unsigned pix = lo + static_cast<unsigned>(lane); pix < hi; pix += 64u) {
-        const unsigned uly = pix / static_cast<unsigned>(tg.w);
+        const unsigned uly = by_w.div(pix);
         const int ly = static_cast<int>(uly);
         const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
         const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
@@ -563,8 +575,8 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
             uint32_t sample_slot = 0;
             const unsigned sidx = s0 + tid;  // sample of the unit, in stream order
             if (sidx < n_samples) {
-                const unsigned pix = pp0 + sidx / static_cast<unsigned>(spp);
-                const unsigned uly = pix / static_cast<unsigned>(tg.w);
+                const unsigned pix = pp0 + UDiv(static_cast<unsigned>(spp)).div(sidx);
+                const unsigned uly = UDiv(static_cast<unsigned>(tg.w)).div(pix);
                 const int ly = static_cast<int>(uly);
                 const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
                 const int px = tg.x + lx, py = tg.y + ly;
@@ -686,7 +698,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
 // level becoming one *record*; then the expensive stages — light samples, shadow rays, shading — run ONCE over
 // all records of all levels, and `resolve` folds each chain's level colours back to front (:143-147)
 // while it sums the pixel's samples.  One launch set per level cost ~40 us of dependent latency per
-// level whatever it held (550 k, 55 k, 5 k, 500, 50 records at 1080p / 4 spp).
+// level whatever it held (320 k, 31 k, 3 k, 300, 30 records at 1080p / 4 spp).
 //
 // Primary hits sit at the front of each unit's slot range (count per unit, no atomics).  Deeper records
 // are appended densely behind index `cap` with ONE workgroup-aggregated atomic per 256-entry block:
@@ -1566,7 +1578,7 @@ static bool soft_sampling(const mcrt_config& c) { return c.soft_shadows && c.sha
 // kFlatMaxBounces reflection levels (1 + maxBounces records per sample slot in the worst case).
 constexpr int kFlatMaxBounces = 8;
 #ifndef MCRT_LIT_LDS_KB
-#define MCRT_LIT_LDS_KB 9
+#define MCRT_LIT_LDS_KB 25
 #endif
 constexpr size_t kLitLdsBytes = MCRT_LIT_LDS_KB * 1024;  // `lit`: LDS for the sample positions of the records whose rays are traced, per pass
 // rare features that need the general kernel variants (one launch set per level, ping-pong queues): per-hit RNG
@@ -1720,7 +1732,12 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
     if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);
+    static const size_t lit_pad = [] {  // development knob: extra dynamic LDS per `lit` workgroup (fewer resident workgroups per CU)
+        const char* e = getenv("MCRT_LIT_LDS_PAD_KB");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? static_cast<size_t>(v) * 1024 : 0;
+    }();
+    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes) + lit_pad, stream, p.scene, p);
 }
 
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {

@@ -989,9 +989,9 @@ DEV int bundle_decide_mesh(const SV& sc, const MeshData& m, int mesh_index, cons
     if (inside || !(m.flags & MESH_OUTER)) return BUNDLE_MISS;
     return BUNDLE_UNKNOWN;
 }
-// Candidates and decisions of one hit in ONE wave-uniform loop over the group roots (scalar mesh data): the exact
+// Candidates and decisions of one hit: a wave-uniform loop over the group roots (scalar mesh data) with the exact
 // moving-away rule and bundle_candidates' conservative segment test on the root's box — both hold for the members
-// inside it — then, for the groups some lane of the wave still needs, bundle_decide_mesh per member.
+// inside it — then bundle_decide_mesh for every member of the groups that are left.
 // Returns the hit's lit count when every candidate is decided — 0 (some mesh stops every ray) or S (no mesh stops
 // any) — else -1; `cand` = the meshes whose rays have to be traced.  decide = false: candidates only.
 // bundle_candidates' segment test with the ray-dependent half prepared once per hit: along one axis the box inflated
@@ -1069,18 +1069,23 @@ DEV int bundle_classify(const SceneView& scg, const SV& sc, V3 O, V3 L, float R,
             seg_axis_apply(cz, O.z, m.lo.z, m.hi.z, s_in, s_out);
         }
         const bool pass = !(away > 0.0f) & !(s_in > s_out);
-        if (!__ballot(pass)) continue;
-        if (!decide) {
-            if (pass) keep |= m.group;
-            continue;
-        }
-        unsigned long long grp = m.group;  // uniform
-        while (grp) {
-            const int j = __builtin_ctzll(grp);
-            grp &= grp - 1ull;
-            const int r = bundle_decide_mesh(sc, mesh_uniform(scg, j), j, g, L, R);
-            dark = dark | (pass & (r == BUNDLE_HIT));
-            if (pass & (r == BUNDLE_UNKNOWN)) keep |= 1ull << j;
+        if (pass) keep |= m.group;
+    }
+    // the decisions, per lane over its own candidates (mesh data from the LDS table: as a wave-uniform loop over the
+    // members with scalar mesh data this part ran fewer instructions and 2 % slower — every lane then waits for the
+    // scalar loads of every mesh some lane needs)
+    if (decide) {
+        unsigned long long rest = keep;
+        keep = 0ull;
+        while (rest) {
+            const int j = __builtin_ctzll(rest);
+            rest &= rest - 1ull;
+            const int r = bundle_decide_mesh(sc, mesh_lane(sc, j), j, g, L, R);
+            if (r == BUNDLE_HIT) {
+                dark = true;
+                break;
+            }
+            if (r == BUNDLE_UNKNOWN) keep |= 1ull << j;
         }
     }
     cand = keep;
