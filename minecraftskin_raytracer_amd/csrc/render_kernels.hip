@@ -1732,12 +1732,7 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
     if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    static const size_t lit_pad = [] {  // development knob: extra dynamic LDS per `lit` workgroup (fewer resident workgroups per CU)
-        const char* e = getenv("MCRT_LIT_LDS_PAD_KB");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? static_cast<size_t>(v) * 1024 : 0;
-    }();
-    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes) + lit_pad, stream, p.scene, p);
+    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);
 }
 
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
