@@ -81,6 +81,18 @@ def test_hand_built_edge_scenes(mcrt, oracle, reference):
         scenes.assert_bit_equal(oracle.render(sd.ptr, cfg), reference.render(sd.ptr, cfg), f"edge scene {kw}")
 
 
+@pytest.mark.parametrize("block", range(3))
+def test_bundle_decision_scenes(mcrt, oracle, reference, block):
+    """The scene types the GPU's whole-bundle shadow decisions are fuzzed on (fuzz_cases.make_bundle_case: hand-built
+    boxes with random texel grids, flat / nested / touching boxes, null textures, lights near and inside them, free pose
+    angles, scaled scenes): the oracle those sweeps trust is the reference's equal on them too."""
+    from fuzz_cases import make_bundle_case
+
+    for seed in range(500 + 40 * block, 500 + 40 * (block + 1)):
+        sd, cfg, what = make_bundle_case(seed)
+        scenes.assert_bit_equal(oracle.render(sd.ptr, cfg), reference.render(sd.ptr, cfg), what)
+
+
 def test_degenerate_cameras_and_lights(mcrt, oracle, reference):
     box = scenes.build_box(scenes.solid((0.8, 0.3, 0.2, 1)), (0, 0, 0), (4, 4, 4))
     for kw in (dict(cam_pos=(0, 10, 0), cam_target=(0, 0, 0)),  # up parallel to forward → zero right vector
