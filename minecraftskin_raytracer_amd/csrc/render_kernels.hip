@@ -176,6 +176,58 @@ __device__ __forceinline__ void background_pixels(const SceneView& sc, const Ren
     }
 }
 
+// A background tile whose every sample has the same colour needs no draws at all: the flat background colour
+// (gradient off, raytracer.cpp:32-33), or the gradient's edge colour when the whole tile lies where the reference's
+// `dist` clamps to 1 — sqrt(cx² + cy²)·2·gradientScale >= 1 for every point a jittered sample of the tile can take
+// (raytracer.cpp:19-24; 18 % of the metric frame's tiles, its corners).  The test uses the tile's rectangle in u,v with a
+// margin of 1e-4, a hundred times the float error of the reference's expression; the colour and the sample sum are
+// formed by the reference's own operations (c = center·(1 - t) + edge·t with t = 1·1; spp additions; · 1/spp).
+__device__ __forceinline__ bool constant_background(const SceneView& sc, const RenderParams& p, const TileGeom& tg, float4& pixel) {
+    const mcrt_config& cfg = p.cfg;
+    C4 c;
+    if (cfg.gradient_bg) {
+        const float fW = static_cast<float>(cfg.width), fH = static_cast<float>(cfg.height);
+        const float ulo = static_cast<float>(tg.x) / fW, uhi = static_cast<float>(tg.x + tg.w) / fW;
+        const float vlo = static_cast<float>(tg.y) / fH, vhi = static_cast<float>(tg.y + tg.h) / fH;
+        const float cx = (ulo <= 0.5f && 0.5f <= uhi) ? 0.0f : fminf(fabsf(ulo - 0.5f), fabsf(uhi - 0.5f));
+        const float cy = (vlo <= 0.5f && 0.5f <= vhi) ? 0.0f : fminf(fabsf(vlo - 0.5f), fabsf(vhi - 0.5f));
+        if (!(__builtin_sqrtf(cx * cx + cy * cy) * 2.0f * cfg.gradient_scale >= 1.0f + 1e-4f)) return false;
+        const float dist = 1.0f;  // sclamp(dist, 0, 1)
+        const float t = dist * dist;
+        c.r = cfg.bg_center[0] * (1.0f - t) + cfg.bg_edge[0] * t;
+        c.g = cfg.bg_center[1] * (1.0f - t) + cfg.bg_edge[1] * t;
+        c.b = cfg.bg_center[2] * (1.0f - t) + cfg.bg_edge[2] * t;
+        c.a = 1.0f;
+    } else {
+        const float* b = sc.hdr->background;
+        c = C4{b[0], b[1], b[2], b[3]};
+    }
+    const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
+    const float inv_spp = 1.0f / static_cast<float>(spp);
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
+    for (int sidx = 0; sidx < spp; ++sidx) {  // tile_renderer.cpp:116-124
+        ar += c.r;
+        ag += c.g;
+        ab += c.b;
+        aa += c.a;
+    }
+    pixel = make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp);
+    return true;
+}
+// the tile's pixels get `pixel`; `nthreads` threads (a wave, or a workgroup), this one being number `tid`
+__device__ __forceinline__ void fill_tile(const RenderParams& p, const TileGeom& tg, float4* __restrict__ out_frame, uchar4* __restrict__ out8, float4 pixel,
+                                          unsigned tid, unsigned nthreads) {
+    const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
+    const UDiv by_w(static_cast<unsigned>(tg.w));
+    for (unsigned pix = tid; pix < npix; pix += nthreads) {
+        const unsigned uly = by_w.div(pix);
+        const int ly = static_cast<int>(uly);
+        const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
+        const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * p.cfg.tile_size + ly) : (tg.y + ly);
+        store_pixel(out_frame, out8, static_cast<size_t>(row) * p.cfg.width + (tg.x + lx), pixel);
+    }
+}
+
 // executed by one wave; `st` = its 2 x 624 words of LDS.  dst != nullptr: the tile's draws go there;
 // dst == nullptr: a background tile, rendered from the draws in LDS.
 __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint32_t* __restrict__ tile_rng, float* __restrict__ dst,
@@ -505,11 +557,14 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
     const SceneView sc = view_of(scene_blob);
     const TilePlan plan = plan_tile(sc, p, tg, tile, lane);
     const size_t stride = p.ws.draws_stride;
-    if (!p.bg_in_plan) {  // every tile's draws to HBM; `primary` renders the background tiles
-        if (p.draws_per_sample > 0) tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(t) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
+    if (!p.bg_in_plan) {  // every tile's draws to HBM; `primary` renders the background tiles (those of one colour need no draws)
+        float4 unused;
+        if (p.draws_per_sample > 0 && !(plan.mask == 0ull && constant_background(sc, p, tg, unused))) tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(t) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
     } else if (plan.mask != 0ull) {  // a tile meshes can touch: its draws, at its touched-tile number
         if (p.draws_per_sample > 0 && plan.ord != ~0u)
             tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(plan.ord) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
+    } else if (float4 pixel; constant_background(sc, p, tg, pixel)) {  // background tile of one colour: no draws, no samples
+        fill_tile(p, tg, out_frame, out8, pixel, static_cast<unsigned>(lane), 64u);
     } else if (p.cfg.samples_per_pixel > 1) {  // background tile, jittered samples
         tile_stream_wave(sc, tile_rng, nullptr, out_frame, out8, p, tg, tile, s_state[wave], lane);
     } else {  // background tile, one centred sample per pixel: no draws at all
@@ -662,6 +717,10 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
         const int tile = tile_base + t;
         if (ws.tile_mask[tile] != 0ull) continue;  // uniform
         const TileGeom tg = tile_of(p, tile);
+        if (float4 pixel; constant_background(scg, p, tg, pixel)) {  // uniform
+            fill_tile(p, tg, out_frame, out8, pixel, static_cast<unsigned>(tid), static_cast<unsigned>(kBlock));
+            continue;
+        }
         const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
         const float* draws = tile_draws + static_cast<size_t>(t) * stride;
         for (unsigned pix = tid; pix < npix; pix += kBlock) {

@@ -47,6 +47,13 @@ def make_case(seed: int):
                   focusDistance=float([0.0, 0.0, 10.0, 45.0, 300.0][g.integers(0, 5)]))
     if g.random() < 0.2:
         kw["gradientBg"] = False
+    # (drawn last: the cases before these lines keep their seeds' meaning)  gradient radii from "the whole frame is edge
+    # colour" to "no pixel reaches it" — tiles of one colour are filled without samples — and unusual colours
+    if g.random() < 0.35:
+        kw["gradientScale"] = float([0.1, 0.5, 0.7071, 1.0, 1.4142, 2.0, 5.0, 0.0][g.integers(0, 8)] * g.uniform(0.98, 1.02))
+    if g.random() < 0.15:
+        kw["bgCenter"] = tuple(float(x) for x in g.uniform(-0.5, 1.5, 4))
+        kw["bgEdge"] = tuple(float(x) for x in np.where(g.random(4) < 0.3, 0.0, g.uniform(-0.5, 1.5, 4)))
     return M.SceneDesc(sc), abi.Config(**kw), f"seed {seed}: {kind} pose {pose} {kw}"
 
 

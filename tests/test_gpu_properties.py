@@ -78,6 +78,35 @@ def test_1080p_sampled_tiles_match_oracle(mcrt, oracle, north_star):
         scenes.assert_bit_equal(f[y:y + h, x:x + w], scratch[y:y + h, x:x + w], f"tile {i} {tiles[i]}")
 
 
+@pytest.mark.parametrize("scale,spp", [(1.0, 4), (0.8, 4), (1.7, 1), (1.0, 13), (0.0, 2)])
+def test_one_colour_background_tiles_match_oracle(mcrt, oracle, north_star, scale, spp):
+    """Background tiles where the gradient's `dist` clamps to 1 for every sample are filled with the edge colour without
+    draws (render_kernels.hip: constant_background): the tiles on both sides of that criterion — the ring where the
+    gradient reaches the edge colour — against the oracle's renderTile, for several radii and sample counts (13 spp:
+    the background goes through `primary`)."""
+    sd, ds, _, _ = north_star
+    cfg = abi.Config(width=1920, height=1080, maxBounces=4, samplesPerPixel=spp, gradientScale=scale)
+    f = render_dev(mcrt, ds, cfg).cpu().numpy()
+    tiles = oracle.generate_tiles(cfg.width, cfg.height, cfg.tileSize)
+
+    def reach(t):  # the smallest gradient distance over the tile's rectangle
+        x, y, w, h = t
+        ulo, uhi, vlo, vhi = x / cfg.width, (x + w) / cfg.width, y / cfg.height, (y + h) / cfg.height
+        cx = 0.0 if ulo <= 0.5 <= uhi else min(abs(ulo - 0.5), abs(uhi - 0.5))
+        cy = 0.0 if vlo <= 0.5 <= vhi else min(abs(vlo - 0.5), abs(vhi - 0.5))
+        return 2.0 * scale * (cx * cx + cy * cy) ** 0.5
+
+    ring = [i for i, t in enumerate(tiles) if 0.93 <= reach(t) <= 1.07]
+    g = np.random.default_rng(int(scale * 100) + spp)
+    pick = list(g.choice(ring, size=min(24, len(ring)), replace=False)) if ring else []
+    pick += [0, 59, len(tiles) - 1, len(tiles) - 60, 30]  # corners, top middle
+    scratch = np.zeros_like(f)
+    for i in pick:
+        oracle.render_tile(sd.ptr, cfg, tiles[i], scratch)
+        x, y, w, h = tiles[i]
+        scenes.assert_bit_equal(f[y:y + h, x:x + w], scratch[y:y + h, x:x + w], f"scale {scale} spp {spp} tile {i} {tiles[i]}")
+
+
 def test_4k_b8_spp16_sampled_tiles_match_oracle(mcrt, oracle, gpu):
     # BASELINE.json configs[2]
     sd = scenes.skin_scene("S64", 0)
