@@ -302,6 +302,10 @@ int mcrt_probe_detmath(int device, int op, const float* x, const float* y, size_
  * Returns the number of mismatching inputs in *mismatches (host side is multi-threaded). */
 int mcrt_probe_detmath_range(int device, int op, uint32_t lo_bits, uint32_t hi_bits, float y0,
                              uint64_t* mismatches);
+/* div_frame — the frame-constant division of the sample coordinates (rt_core.h) — against the general division on the
+ * device, for the integer divisors d_first .. d_first + d_count - 1 and every float a sample coordinate can take
+ * (0 and 2^-33 .. d + 1); mode 1 checks the one-correction form instead.  tools/gpu_verify_div.py */
+int mcrt_probe_div_const(int device, uint32_t d_first, uint32_t d_count, int mode, uint64_t* mismatches, uint32_t* a_failing_divisor);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "mcrt_unpack_rows_device", "mcrt_quantize_rgba8_device", "mcrt_quantize_rgba8", "mcrt_last_timings",
     "mcrt_time_render_device", "mcrt_build_skin_scene", "mcrt_build_default_scene", "mcrt_builtin_pose",
     "mcrt_scene_desc_free", "mcrt_scene_flatten", "mcrt_probe_intersect", "mcrt_probe_trace",
-    "mcrt_probe_mt_uniform", "mcrt_probe_detmath", "mcrt_probe_detmath_range",
+    "mcrt_probe_mt_uniform", "mcrt_probe_detmath", "mcrt_probe_detmath_range", "mcrt_probe_div_const",
     "mcrt_render_device_ex", "mcrt_write_png_rgba8", "mcrt_encode_png_rgba8", "mcrt_write_png_f32", "mcrt_render_png",
     "mcrt_assemble_frame_device", "mcrt_scene_set_lanes", "mcrt_trim", "mcrt_scene_check", "mcrt_render_multi",
 ]
@@ -78,6 +78,7 @@ def load():
         "mcrt_probe_mt_uniform": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int, f_p]),
         "mcrt_probe_detmath": (C.c_int, [C.c_int, C.c_int, f_p, f_p, C.c_size_t, f_p]),
         "mcrt_probe_detmath_range": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_uint64)]),
+        "mcrt_probe_div_const": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -257,6 +257,15 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
         p.bundle_decisions = decisions ? 1 : 0;
     }
     p.cfg = *cfg;
+    if (cfg->width > 0 && cfg->height > 0) {
+        p.inv_width = 1.0f / static_cast<float>(cfg->width);
+        p.inv_height = 1.0f / static_cast<float>(cfg->height);
+        static const bool fast_div = [] {  // development knob: MCRT_DIV_FRAME=0 takes the general division everywhere
+            const char* e = std::getenv("MCRT_DIV_FRAME");
+            return !(e && e[0] == '0');
+        }();
+        p.div_frame = (fast_div && cfg->width <= kDivFrameMax && cfg->height <= kDivFrameMax) ? 1 : 0;
+    }
     p.shard = make_shard(*cfg, first + li * step, step * n_lanes);
     p.shard.pack_first = li;
     p.shard.pack_step = n_lanes;
@@ -1327,6 +1336,26 @@ int mcrt_probe_detmath(int device, int op, const float* x, const float* y, size_
     dy.release();
     dout.release();
     if (e != hipSuccess) return hip_fail(e, "probe_detmath");
+    return MCRT_OK;
+}
+
+int mcrt_probe_div_const(int device, uint32_t d_first, uint32_t d_count, int mode, uint64_t* mismatches, uint32_t* a_failing_divisor) {
+    if (!mismatches || d_first == 0 || d_count == 0 || d_count > 65535u) return fail(MCRT_ERR_INVALID, "bad argument");
+    if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    DeviceBuffer counts;
+    HIP_TRY(counts.reserve(16));
+    hipError_t e = hipMemset(counts.ptr, 0, 16);
+    for (uint32_t off = 0; e == hipSuccess && off < d_count; off += 32) {  // ~12 G quotients per launch
+        e = launch_probe_div_const(d_first + off, d_count - off < 32u ? d_count - off : 32u, mode, static_cast<unsigned long long*>(counts.ptr), nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    unsigned long long host[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(host, counts.ptr, 16, hipMemcpyDeviceToHost);
+    counts.release();
+    if (e != hipSuccess) return hip_fail(e, "probe_div_const");
+    *mismatches = host[0];
+    if (a_failing_divisor) *a_failing_divisor = static_cast<uint32_t>(host[1]);
     return MCRT_OK;
 }
 

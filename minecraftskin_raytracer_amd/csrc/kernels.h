@@ -76,6 +76,9 @@ struct WaveSpace {
 // lie in a window around zero (|sum| < 4 M for the character scene): a table of mt[397] for the seeds
 // -2^24 .. 2^24 - 1 (wrapping) is 128 MB per device, built once with the same recurrence in ~2 ms, and replaces
 // the chain by one 4-byte load.  Seeds outside the window run the chain.
+// integer divisors (frame widths and heights) for which rt::div_frame has been checked exhaustively against the general division
+constexpr int kDivFrameMax = 16384;
+
 constexpr uint32_t kSeedWindowHalf = 1u << 24;
 constexpr uint32_t kSeedWindow = 1u << 25;  // table entries: seed s at index s + kSeedWindowHalf (mod 2^32)
 
@@ -103,6 +106,8 @@ struct RenderParams {
     int lit_lds_offset;    // `lit`: byte offset of that area in dynamic LDS (behind the scene tables, 16-aligned)
     int lit_lds_bytes;     // `lit`: its size
     int flat;              // 1: flat pipeline (all levels' records shaded at once); 0: general variants, one launch set per level
+    float inv_width, inv_height;  // 1.0f / width, 1.0f / height (correctly rounded: formed on the host)
+    int div_frame;         // 1: width and height lie in rt::div_frame's verified range (rt_core.h)
     int bundle_decisions;  // `lit`: 1 — a hit whose whole bundle of shadow rays is decided (rt::bundle_decide) draws no light
                            //    samples and traces no rays; 0 (MCRT_BUNDLE_DECISIONS=0) — every hit's rays are traced
 };
@@ -144,6 +149,7 @@ hipError_t launch_assemble_frame(const mcrt_config& cfg, int world, const float*
 hipError_t launch_quantize(const float* rgba, uint8_t* out, size_t n_pixels, hipStream_t stream);
 // fills table[i] = mt[397] of std::mt19937(i - kSeedWindowHalf) for i < kSeedWindow
 hipError_t launch_build_seed_table(uint32_t* table, hipStream_t stream);
+hipError_t launch_probe_div_const(uint32_t d_first, uint32_t d_count, int mode, unsigned long long* counts, hipStream_t stream);
 
 // probes
 hipError_t launch_probe_intersect(const uint8_t* scene, const float* rays, int n, mcrt_hit* out,

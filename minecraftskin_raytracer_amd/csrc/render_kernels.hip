@@ -66,6 +66,17 @@ struct UDiv {
     __device__ __forceinline__ unsigned div(unsigned n) const { return shift >= 0 ? n >> shift : n / d; }
 };
 
+// (px + jitter) / width and (py + jitter) / height of a sample (tile_renderer.cpp:88-89): rt::div_frame where the
+// frame's size lies in its verified range, the general division otherwise
+struct FrameDiv {
+    float w, h, rw, rh;
+    bool fast;
+    __device__ __forceinline__ explicit FrameDiv(const RenderParams& p)
+        : w(static_cast<float>(p.cfg.width)), h(static_cast<float>(p.cfg.height)), rw(p.inv_width), rh(p.inv_height), fast(p.div_frame != 0) {}
+    __device__ __forceinline__ float u(float x) const { return fast ? div_frame(x, w, rw) : x / w; }
+    __device__ __forceinline__ float v(float y) const { return fast ? div_frame(y, h, rh) : y / h; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // tile geometry helpers (TileRenderer::generateTiles, tile_renderer.cpp:18-39)
 // ---------------------------------------------------------------------------------------------
@@ -148,7 +159,7 @@ __device__ __forceinline__ void background_pixels(const SceneView& sc, const Ren
     const mcrt_config& cfg = p.cfg;
     const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const unsigned dd = static_cast<unsigned>(p.draws_per_sample);
-    const float fW = static_cast<float>(cfg.width), fH = static_cast<float>(cfg.height);
+    const FrameDiv fd(p);
     const float inv_spp = 1.0f / static_cast<float>(spp);
     const UDiv by_w(static_cast<unsigned>(tg.w));
     for (unsigned pix = lo + static_cast<unsigned>(lane); pix < hi; pix += 64u) {
@@ -164,7 +175,7 @@ __device__ __forceinline__ void background_pixels(const SceneView& sc, const Ren
                 jx = draw(g0 + static_cast<unsigned>(sidx) * dd);
                 jy = draw(g0 + static_cast<unsigned>(sidx) * dd + 1u);
             }
-            const C4 c = background(sc, cfg, (fx + jx) / fW, (fy + jy) / fH);  // tile_renderer.cpp:111-114
+            const C4 c = background(sc, cfg, fd.u(fx + jx), fd.v(fy + jy));  // tile_renderer.cpp:111-114
             ar += c.r;
             ag += c.g;
             ab += c.b;
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
     const int dd = p.draws_per_sample;
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
     const float aspect = static_cast<float>(cfg.width) / static_cast<float>(cfg.height);
-    const float fW = static_cast<float>(cfg.width), fH = static_cast<float>(cfg.height);
+    const FrameDiv fd(p);
     float focusDist = cfg.focus_distance;
     if (focusDist <= 0.0f) focusDist = sc.hdr->cam_focus_auto;
     const float inv_spp = 1.0f / static_cast<float>(spp);
@@ -643,8 +654,8 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                     jy = jd[1];
                     dpos = 2;
                 }
-                const float su = (static_cast<float>(px) + jx) / fW;
-                const float sv = (static_cast<float>(py) + jy) / fH;
+                const float su = fd.u(static_cast<float>(px) + jx);
+                const float sv = fd.v(static_cast<float>(py) + jy);
                 sample_slot = slot_base + sidx;
                 ray = dof ? lens_ray(sc, su, sv, aspect, cfg.aperture, focusDist, jd[dpos], jd[dpos + 1])
                           : camera_ray(sc, su, sv, aspect);
@@ -736,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                     jx = jd[sidx * dd];
                     jy = jd[sidx * dd + 1];
                 }
-                const C4 c = background(sc, cfg, (fx + jx) / fW, (fy + jy) / fH);  // tile_renderer.cpp:111-114
+                const C4 c = background(sc, cfg, fd.u(fx + jx), fd.v(fy + jy));  // tile_renderer.cpp:111-114
                 ar += c.r;
                 ag += c.g;
                 ab += c.b;
@@ -1608,9 +1619,35 @@ __global__ void probe_detmath_range_kernel(int op, uint32_t lo_bits, uint64_t co
     out[i] = detmath_op(op, mcrt_u2f(lo_bits + static_cast<uint32_t>(i)), y0);
 }
 
+// div_frame against the general division for the divisors d_first .. d_first + gridDim.y - 1 and every float x in
+// {0} and [2^-33, d + 1] (by bit pattern).  counts[0] += mismatches, counts[1] = a failing divisor
+__global__ void probe_div_const_kernel(uint32_t d_first, int mode, unsigned long long* counts) {
+    const float d = static_cast<float>(d_first + blockIdx.y);
+    const float rd = 1.0f / d;
+    const uint32_t lo = 0x2f000000u /* 2^-33 */, hi = __float_as_uint(d + 1.0f);
+    unsigned long long bad = 0;
+    for (uint64_t b = static_cast<uint64_t>(lo) + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b <= hi + 1ull;
+         b += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const float x = b > hi ? 0.0f : __uint_as_float(static_cast<uint32_t>(b));
+        const float want = x / d;
+        const float got = mode == 2 ? x * rd : (mode ? div_frame2(x, d, rd) : div_frame(x, d, rd));  // mode 1: two corrections; mode 2: none (the probe's own check)
+        if (__float_as_uint(want) != __float_as_uint(got)) ++bad;
+    }
+    if (bad) {
+        atomicAdd(&counts[0], bad);
+        counts[1] = d_first + blockIdx.y;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+hipError_t launch_probe_div_const(uint32_t d_first, uint32_t d_count, int mode, unsigned long long* counts, hipStream_t stream) {
+    if (d_count == 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_div_const_kernel, dim3(2048, d_count), dim3(256), 0, stream, d_first, mode, counts);
+    return hipGetLastError();
+}
+
 Shard make_shard(const mcrt_config& cfg, int first, int step) {
     Shard s{};
     s.first = first;

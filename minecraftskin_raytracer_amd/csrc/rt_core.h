@@ -60,6 +60,22 @@ DEV float rcp_exact(float x) {
     const float e = __builtin_fmaf(-x, r, 1.0f);
     return __builtin_fmaf(e, r, r);
 }
+// x / d for a divisor that stays the same for a whole frame — its width and height, `(px + jitter) / width`
+// (tile_renderer.cpp:88-89), two divisions per sample — given rd = 1.0f / d rounded correctly (formed on the host): the
+// product with the reciprocal and ONE Newton correction with fused multiply-adds (the residual x - q·d of a nearly
+// correct quotient is exact), 3 instructions instead of the ~11 of the general expansion.  Not a numerical argument:
+// for every integer divisor up to kDivFrameMax (kernels.h) the equality with the IEEE quotient has been checked on the device for
+// EVERY float x a sample coordinate can take (0 and 2^-33 … d + 1; 6·10¹² quotients: tools/gpu_verify_div.py,
+// mcrt_probe_div_const, result under profiles/) — larger frames take the general division.  (div_frame2, with the
+// second correction that Markstein's theorem asks for in general, passes the same check and is not needed.)
+DEV float div_frame(float x, float d, float rd) {
+    const float q0 = x * rd;
+    return __builtin_fmaf(__builtin_fmaf(-q0, d, x), rd, q0);
+}
+DEV float div_frame2(float x, float d, float rd) {  // probe only
+    const float q1 = div_frame(x, d, rd);
+    return __builtin_fmaf(__builtin_fmaf(-q1, d, x), rd, q1);
+}
 DEV V3 vdiv(V3 a, float s) {  // vec3.h:22 — callers guarantee 1e-8 <= s (normalize, isInShadow)
     float inv = rcp_exact(s);
     return V3{a.x * inv, a.y * inv, a.z * inv};

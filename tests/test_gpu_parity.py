@@ -40,6 +40,23 @@ def test_fast_reciprocal_is_the_ieee_reciprocal(mcrt, gpu):
     assert mcrt.probe_detmath_range(5, lo | 0x80000000, hi | 0x80000000) == 0
 
 
+def test_frame_division_is_the_ieee_division(mcrt, gpu):
+    """rt::div_frame ((px + jitter) / width as a product with 1/width and one FMA correction) against the general
+    division for EVERY float a sample coordinate can take (0 and 2^-33 .. d + 1): the frame sizes of BASELINE.json, the
+    ends of the verified range and a block of 300 odd sizes; tools/gpu_verify_div.py covers every divisor up to 16384
+    (profiles/r02_v5/div_const_exhaustive.txt).  The probe itself is checked with the uncorrected product."""
+    from minecraftskin_raytracer_amd import api
+
+    for d in (1, 2, 3, 256, 1080, 1920, 2160, 3840, 4320, 7680, 16383, 16384):
+        assert api.probe_div_const(d, 1) == (0, 0), d
+    assert api.probe_div_const(601, 300) == (0, 0)
+    import ctypes as C
+    from minecraftskin_raytracer_amd import _lib
+
+    bad, which = C.c_uint64(), C.c_uint32()
+    assert _lib.load().mcrt_probe_div_const(0, 1920, 1, 2, C.byref(bad), C.byref(which)) == 0 and bad.value > 1000000
+
+
 def test_detmath_device_random(mcrt, gpu):
     g = np.random.default_rng(1)
     x = g.uniform(-200, 200, 1 << 16).astype(np.float32)
