@@ -328,10 +328,10 @@ def probe_detmath_range(op: int, lo_bits: int, hi_bits: int, y0: float = 0.0, de
     return int(bad.value)
 
 
-def probe_div_const(d_first: int, d_count: int, short_form: bool = False, device: int = 0):
+def probe_div_const(d_first: int, d_count: int, two_corrections: bool = False, device: int = 0):
     """(mismatches, a failing divisor or 0): rt::div_frame against the general division, exhaustively (mcrt.h)."""
     bad, which = C.c_uint64(), C.c_uint32()
-    check(load().mcrt_probe_div_const(device, d_first, d_count, 1 if short_form else 0, C.byref(bad), C.byref(which)))
+    check(load().mcrt_probe_div_const(device, d_first, d_count, 1 if two_corrections else 0, C.byref(bad), C.byref(which)))
     return int(bad.value), int(which.value)
 
 
