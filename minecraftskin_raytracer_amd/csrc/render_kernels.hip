@@ -1624,6 +1624,17 @@ __global__ void probe_detmath_range_kernel(int op, uint32_t lo_bits, uint64_t co
 __global__ void probe_div_const_kernel(uint32_t d_first, int mode, unsigned long long* counts) {
     const float d = static_cast<float>(d_first + blockIdx.y);
     const float rd = 1.0f / d;
+    if (mode == 3) {  // rt::sqrt_unit against sqrtf for 0 and every float in [2^-64, 2) (the divisor plays no part)
+        unsigned long long bad = 0;
+        const uint32_t lo = 0x1f800000u /* 2^-64 */, hi = 0x3fffffffu;
+        for (uint64_t b = static_cast<uint64_t>(lo) + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b <= hi + 1ull;
+             b += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+            const float x = b > hi ? 0.0f : __uint_as_float(static_cast<uint32_t>(b));
+            if (__float_as_uint(__builtin_sqrtf(x)) != __float_as_uint(sqrt_unit(x))) ++bad;
+        }
+        if (bad) atomicAdd(&counts[0], bad);
+        return;
+    }
     const uint32_t lo = 0x2f000000u /* 2^-33 */, hi = __float_as_uint(d + 1.0f);
     unsigned long long bad = 0;
     for (uint64_t b = static_cast<uint64_t>(lo) + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b <= hi + 1ull;

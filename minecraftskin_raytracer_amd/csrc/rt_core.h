@@ -72,6 +72,19 @@ DEV float div_frame(float x, float d, float rd) {
     const float q0 = x * rd;
     return __builtin_fmaf(__builtin_fmaf(-q0, d, x), rd, q0);
 }
+// sqrtf for 0 and 2^-64 <= x < 2 — the gradient's cx² + cy² with |cx|, |cy| <= 0.5 is 0 or at least 2^-50
+// (raytracer.cpp:19-22) — as the compiler forms the correctly rounded root (hardware estimate within one ulp, then the
+// choice among its two neighbours by the signs of the fused residuals) without the rescaling of tiny arguments and the
+// class test that the general expansion spends 7 of its 16 instructions on.  Checked against it for every float of
+// the range on the device (mcrt_probe_div_const mode 3, tests/test_gpu_parity.py).
+DEV float sqrt_unit(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_lo = __builtin_fmaf(-lo, s, x), r_hi = __builtin_fmaf(-hi, s, x);
+    float r = (0.0f >= r_lo) ? lo : s;
+    r = (0.0f < r_hi) ? hi : r;
+    return r;
+}
 DEV float div_frame2(float x, float d, float rd) {  // probe only
     const float q1 = div_frame(x, d, rd);
     return __builtin_fmaf(__builtin_fmaf(-q1, d, x), rd, q1);
@@ -1323,7 +1336,7 @@ template <class SV>
 DEV C4 background(const SV& sc, const mcrt_config& cfg, float u, float v) {  // :16-34
     if (cfg.gradient_bg) {
         float cx = u - 0.5f, cy = v - 0.5f;
-        float dist = __builtin_sqrtf(cx * cx + cy * cy) * 2.0f * cfg.gradient_scale;
+        float dist = sqrt_unit(cx * cx + cy * cy) * 2.0f * cfg.gradient_scale;  // u, v in [0, 1]: the argument is 0 or in [2^-50, 0.5]
         dist = sclamp(dist, 0.0f, 1.0f);
         float t = dist * dist;
         C4 c;

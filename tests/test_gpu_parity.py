@@ -55,6 +55,8 @@ def test_frame_division_is_the_ieee_division(mcrt, gpu):
 
     bad, which = C.c_uint64(), C.c_uint32()
     assert _lib.load().mcrt_probe_div_const(0, 1920, 1, 2, C.byref(bad), C.byref(which)) == 0 and bad.value > 1000000
+    # rt::sqrt_unit (the gradient's square root without the general expansion's rescaling): 0 and every float in [2^-64, 2)
+    assert _lib.load().mcrt_probe_div_const(0, 1, 1, 3, C.byref(bad), C.byref(which)) == 0 and bad.value == 0
 
 
 def test_detmath_device_random(mcrt, gpu):
