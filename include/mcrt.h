@@ -305,7 +305,7 @@ int mcrt_probe_detmath_range(int device, int op, uint32_t lo_bits, uint32_t hi_b
 /* div_frame — the frame-constant division of the sample coordinates (rt_core.h) — against the general division on the
  * device, for the integer divisors d_first .. d_first + d_count - 1 and every float a sample coordinate can take
  * (0 and 2^-33 .. d + 1); mode 1 checks the form with a second correction, mode 2 the uncorrected product (the probe's
- * own check); mode 3: rt::sqrt_unit against sqrtf for 0 and every float in [2^-64, 2).  tools/gpu_verify_div.py */
+ * own check); mode 3: rt::sqrt_pos against sqrtf for 0 and every float from 2^-96 to infinity.  tools/gpu_verify_div.py */
 int mcrt_probe_div_const(int device, uint32_t d_first, uint32_t d_count, int mode, uint64_t* mismatches, uint32_t* a_failing_divisor);
 
 #ifdef __cplusplus

@@ -1322,8 +1322,8 @@ __global__ __launch_bounds__(kBlock, MCRT_AO_WAVES) void ao_kernel(const uint8_t
             for (int i = 0; i < A; ++i) {
                 const float r1 = rng.uniform();
                 const float r2 = rng.uniform();
-                const float sinT = __builtin_sqrtf(1.0f - r1);
-                const float cosT = __builtin_sqrtf(r1);
+                const float sinT = sqrt_pos(1.0f - r1);
+                const float cosT = sqrt_pos(r1);
                 float sn, cs;
                 mcrt_sincosf(kTwoPi * r2, &sn, &cs);
                 const V3 local = mk(sinT * cs, cosT, sinT * sn);
@@ -1624,13 +1624,13 @@ __global__ void probe_detmath_range_kernel(int op, uint32_t lo_bits, uint64_t co
 __global__ void probe_div_const_kernel(uint32_t d_first, int mode, unsigned long long* counts) {
     const float d = static_cast<float>(d_first + blockIdx.y);
     const float rd = 1.0f / d;
-    if (mode == 3) {  // rt::sqrt_unit against sqrtf for 0 and every float in [2^-64, 2) (the divisor plays no part)
+    if (mode == 3) {  // rt::sqrt_pos against sqrtf for 0 and every float from 2^-96 to infinity (the divisor plays no part)
         unsigned long long bad = 0;
-        const uint32_t lo = 0x1f800000u /* 2^-64 */, hi = 0x3fffffffu;
+        const uint32_t lo = 0x0f800000u /* 2^-96 */, hi = 0x7f800000u;
         for (uint64_t b = static_cast<uint64_t>(lo) + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b <= hi + 1ull;
              b += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
             const float x = b > hi ? 0.0f : __uint_as_float(static_cast<uint32_t>(b));
-            if (__float_as_uint(__builtin_sqrtf(x)) != __float_as_uint(sqrt_unit(x))) ++bad;
+            if (__float_as_uint(__builtin_sqrtf(x)) != __float_as_uint(sqrt_pos(x))) ++bad;
         }
         if (bad) atomicAdd(&counts[0], bad);
         return;

@@ -72,12 +72,15 @@ DEV float div_frame(float x, float d, float rd) {
     const float q0 = x * rd;
     return __builtin_fmaf(__builtin_fmaf(-q0, d, x), rd, q0);
 }
-// sqrtf for 0 and 2^-64 <= x < 2 — the gradient's cx² + cy² with |cx|, |cy| <= 0.5 is 0 or at least 2^-50
-// (raytracer.cpp:19-22) — as the compiler forms the correctly rounded root (hardware estimate within one ulp, then the
-// choice among its two neighbours by the signs of the fused residuals) without the rescaling of tiny arguments and the
-// class test that the general expansion spends 7 of its 16 instructions on.  Checked against it for every float of
-// the range on the device (mcrt_probe_div_const mode 3, tests/test_gpu_parity.py).
-DEV float sqrt_unit(float x) {
+// sqrtf for x = 0 and every x >= 2^-96 (infinity included), as the compiler forms the correctly rounded root — hardware
+// estimate within one ulp, then the choice among its two neighbours by the signs of the fused residuals — without the
+// rescaling of arguments below 2^-96 and the class test that the general expansion spends 7 of its 16 instructions on.
+// Checked against it for EVERY float of that range on the device (mcrt_probe_div_const mode 3,
+// test_frame_division_is_the_ieee_division).  Below 2^-96 the result is merely some number below 2^-47, which is
+// all the callers need there: squared lengths that small fall under normalize's 1e-8 and isInShadow's 1e-6
+// thresholds (vec3.h:46-50, shading.cpp:19), and the other arguments — the gradient's cx² + cy², draws k·2^-32 and
+// 1 - draw — are 0 or at least 2^-50.
+DEV float sqrt_pos(float x) {
     const float s = __builtin_amdgcn_sqrtf(x);
     const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
     const float r_lo = __builtin_fmaf(-lo, s, x), r_hi = __builtin_fmaf(-hi, s, x);
@@ -97,7 +100,7 @@ DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV V3 cross(V3 a, V3 b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-DEV float length(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+DEV float length(V3 a) { return sqrt_pos(a.x * a.x + a.y * a.y + a.z * a.z); }
 DEV V3 normalize(V3 a) {  // vec3.h:46-50
     float l = length(a);
     if (l < 1e-8f) return V3{0.0f, 0.0f, 0.0f};
@@ -871,7 +874,7 @@ DEV BundleGeom bundle_geom(V3 O, V3 L, float R, float rot_slop) {
     const float Rb = R * 1.001f + 2e-6f * (max3abs(L) + g.omax + R) + rot_slop * (max3abs(D) + R) + 1e-30f;
     g.nlo = mk(D.x - Rb, D.y - Rb, D.z - Rb);
     g.nhi = mk(D.x + Rb, D.y + Rb, D.z + Rb);
-    const float dc = __builtin_sqrtf(dot(D, D));
+    const float dc = __builtin_amdgcn_sqrtf(dot(D, D));  // (an estimate will do: the bounds carry 1e-5)
     g.dist_lo = dc * (1.0f - 1e-5f) - Rb;
     g.dist_hi = dc * (1.0f + 1e-5f) + Rb;
     g.ok = g.dist_lo > 1e-3f && g.dist_hi < 1e18f;  // isInShadow's `distToLight < 1e-6` exit is never taken
@@ -1252,7 +1255,7 @@ DEV LightFrame light_frame(const SV& sc, V3 point) {
 template <class SV>
 DEV V3 light_sample_on_frame(const SV& sc, const LightFrame& f, float d0, float d1) {
     float angle = kTwoPi * d0;
-    float rr = sc.hdr->light_radius * __builtin_sqrtf(d1);
+    float rr = sc.hdr->light_radius * sqrt_pos(d1);  // a draw: 0 or at least 2^-32
     // inlined libm kernels: calls here would serialise the independent samples of a hit
     float sn, cs;
     mcrt_sincosf(angle, &sn, &cs);
@@ -1336,7 +1339,7 @@ template <class SV>
 DEV C4 background(const SV& sc, const mcrt_config& cfg, float u, float v) {  // :16-34
     if (cfg.gradient_bg) {
         float cx = u - 0.5f, cy = v - 0.5f;
-        float dist = sqrt_unit(cx * cx + cy * cy) * 2.0f * cfg.gradient_scale;  // u, v in [0, 1]: the argument is 0 or in [2^-50, 0.5]
+        float dist = sqrt_pos(cx * cx + cy * cy) * 2.0f * cfg.gradient_scale;  // u, v in [0, 1]: the argument is 0 or in [2^-50, 0.5]
         dist = sclamp(dist, 0.0f, 1.0f);
         float t = dist * dist;
         C4 c;
@@ -1362,8 +1365,8 @@ DEV float ambient_occlusion(const SV& sc, V3 point, V3 normal, int samples, floa
     for (int i = 0; i < samples; ++i) {
         float r1 = rng.uniform();
         float r2 = rng.uniform();
-        float sinT = __builtin_sqrtf(1.0f - r1);
-        float cosT = __builtin_sqrtf(r1);
+        float sinT = sqrt_pos(1.0f - r1);
+        float cosT = sqrt_pos(r1);
         float phi = kTwoPi * r2;
         const SinCos sc_phi = dev_sincosf(phi);
         V3 local = mk(sinT * sc_phi.c, cosT, sinT * sc_phi.s);
@@ -1476,7 +1479,7 @@ DEV Ray lens_ray(const SV& sc, float u, float v, float aspect, float aperture, f
     const FlatHeader* h = sc.hdr;
     V3 focus = pin.o + pin.d * focusDist;
     float angle = kTwoPi * d0;
-    float radius = aperture * __builtin_sqrtf(d1);
+    float radius = aperture * sqrt_pos(d1);
     const SinCos sc_lens = dev_sincosf(angle);
     float lx = radius * sc_lens.c;
     float ly = radius * sc_lens.s;

@@ -55,7 +55,7 @@ def test_frame_division_is_the_ieee_division(mcrt, gpu):
 
     bad, which = C.c_uint64(), C.c_uint32()
     assert _lib.load().mcrt_probe_div_const(0, 1920, 1, 2, C.byref(bad), C.byref(which)) == 0 and bad.value > 1000000
-    # rt::sqrt_unit (the gradient's square root without the general expansion's rescaling): 0 and every float in [2^-64, 2)
+    # rt::sqrt_pos (square roots without the general expansion's rescaling of tiny arguments): 0 and every float from 2^-96 to infinity
     assert _lib.load().mcrt_probe_div_const(0, 1, 1, 3, C.byref(bad), C.byref(which)) == 0 and bad.value == 0
 
 
