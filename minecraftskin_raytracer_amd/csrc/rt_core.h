@@ -219,8 +219,8 @@ DEV uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far) {
 }
 // uniform_real_distribution<float>(0,1): float(x) * 2^-32, >= 1 → nextafter(1, 0)
 DEV float mt_to_unit(uint32_t x) {
-    float r = static_cast<float>(x) * 0x1p-32f;
-    return (r >= 1.0f) ? 0x1.fffffep-1f : r;
+    const float r = static_cast<float>(x) * 0x1p-32f;  // in [0, 1]
+    return __builtin_fminf(r, 0x1.fffffep-1f);         // (r >= 1) ? nextafter(1, 0) : r
 }
 
 constexpr int kMtShortMax = 227;  // draws available from the two-recurrence form
