@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                     const float4 bd = s_bd[tid], bp = s_bp[tid], bn = s_bn[tid];
                     root = __float_as_uint(bd.w);
                     nray = reflect_ray(mk(bd.x, bd.y, bd.z), mk(bp.x, bp.y, bp.z), mk(bn.x, bn.y, bn.z));
-                    nhit = hit_scene(sc, nray, ~0ull);
+                    nhit = hit_scene<true>(sc, nray, ~0ull);
                     if (nhit.hit)
                         next_hit = true;
                     else
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void chase_kernel(const 
                     active = false;
                 } else {
                     nray = reflect_ray(r.d, r.p, r.n);
-                    nhit = hit_scene(sc, nray, ~0ull);
+                    nhit = hit_scene<true>(sc, nray, ~0ull);
                     if (nhit.hit) {
                         next_hit = true;
                     } else {
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
                 done = true;
             } else {
                 nray = reflect_ray(r.ray, r.hit);
-                nhit = hit_scene(sc, nray, ~0ull);
+                nhit = hit_scene<true>(sc, nray, ~0ull);
                 if (nhit.hit) {  // the chain goes on: its level colour waits on the stack for the fold
                     ws.stack[static_cast<size_t>(depth) * ws.cap + root] = make_float4(c.r, c.g, c.b, c.a);
                     next_hit = true;

@@ -650,7 +650,11 @@ DEV bool mesh_candidate(const SV& sc, const MeshData& m, int mesh_index, const R
 // tested (flat_scene.h: a root's box contains its members' boxes); a passing root takes its members
 // along — phase 2 is exact, phase 1 only has to be conservative.  The loop index is wave-uniform
 // (scalar loads); meshes beyond 63 are handled by the callers' tail loops.
-template <class SV>
+// kLeaving (reflection rays: nine in ten leave the figure): an un-posed root is first asked whether the ray moves away
+// from it — its origin beyond a face and its direction not towards it on that axis, which makes both slab distances of
+// the axis negative or the axis "parallel" with the origin outside (intersection.cpp:222-249): the slab test's own
+// verdict from two comparisons per axis — and the slab test is skipped when that holds for every lane of the wave.
+template <bool kLeaving = false, class SV>
 DEV unsigned long long scene_candidates(const SV& sc, const RayQ& q, unsigned long long mesh_mask, float t_limit) {
     unsigned long long cand = 0ull;
     const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
@@ -660,6 +664,12 @@ DEV unsigned long long scene_candidates(const SV& sc, const RayQ& q, unsigned lo
         if (!((roots >> i) & 1ull)) continue;
         const MeshData m = mesh_uniform(sc, i);
         if (!(m.group & mesh_mask)) continue;  // uniform: the mask is per tile
+        if (kLeaving && !(SV::kPosed && (m.flags & MESH_ROTATED)) && !(m.flags & MESH_EMPTY)) {
+            // beyond the max face: every d > -1e-8 (away, or "parallel": |d| < 1e-8, :222); beyond the min face: every d < 1e-8
+            const bool away = ((q.o.x > m.hi.x) & (q.d.x > -1e-8f)) | ((q.o.x < m.lo.x) & (q.d.x < 1e-8f)) | ((q.o.y > m.hi.y) & (q.d.y > -1e-8f)) |
+                              ((q.o.y < m.lo.y) & (q.d.y < 1e-8f)) | ((q.o.z > m.hi.z) & (q.d.z > -1e-8f)) | ((q.o.z < m.lo.z) & (q.d.z < 1e-8f));
+            if (!__ballot(!away)) continue;
+        }
         if (mesh_may_hit<SV::kPosed>(m, q, t_limit)) cand |= m.group;
     }
     return cand & mesh_mask;
@@ -667,7 +677,7 @@ DEV unsigned long long scene_candidates(const SV& sc, const RayQ& q, unsigned lo
 
 // intersectScene :408-421.  mesh_mask: bit i set → mesh i is tested (primary-ray culling; all
 // ones for secondary rays).  Meshes beyond bit 63 are always tested.
-template <class SV>
+template <bool kLeaving = false, class SV>
 DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
     const RayQ q = prepare(r);
     Cand best;
@@ -679,7 +689,7 @@ DEV Hit hit_scene(const SV& sc, const Ray& r, uint64_t mesh_mask) {
     best.back = false;
     int best_mesh = -1;
     // per lane: ascending mesh index, strictly smaller t wins → first mesh on ties, like the reference
-    unsigned long long cand = scene_candidates(sc, q, mesh_mask, kFltMax);
+    unsigned long long cand = scene_candidates<kLeaving>(sc, q, mesh_mask, kFltMax);
     while (cand) {
         const int i = __builtin_ctzll(cand);
         cand &= cand - 1ull;
