@@ -14,9 +14,11 @@ framebuffer in HBM.  Three figures describe it, all in the line:
   latency_ms            one frame at a time on the device: enqueue, wait, repeat (library defaults: the render
                         spreads itself over 2 internal streams); kernel.pipeline_ms is the same frame on ONE
                         stream, measured with hipEvents on that stream.
-  render_call           SURVEY.md §8(d)'s metric: wall time of ONE `TileRenderer::render()` call through the C ABI
-                        (mcrt_render: scene flatten + upload + kernels + download into host memory + progress
-                        callbacks), median of >= 10 calls after 2 warm-ups, with the library's own split.
+  render_call           SURVEY.md §8(d)'s metric — THE CONTRACT'S t: wall time of ONE `TileRenderer::render()` call
+                        (scene flatten + upload + kernels + download into host memory + progress callbacks) returning a
+                        FRESH Image, as the reference's call site gets one (tile_renderer.cpp:141), median of >= 10 calls
+                        after 2 warm-ups, with the library's own split; beside it the same call into a reused buffer, the
+                        first call of a cold process, and the C++ drop-in binary (tools/micro/dropin_time.cpp).
 
 N > 1 (launched by torch.distributed.run, one process per GPU): the SAME frame is sharded by cyclic tile
 rows (rank r renders tile rows r, r+N, ...), each rank renders into a packed buffer and an RCCL gather over
@@ -70,9 +72,25 @@ def workload_config(M, name: str):
     return M.Config(width=w, height=h, maxBounces=b, samplesPerPixel=spp, **(extra[0] if extra else {})), skin, pose
 
 
-def cpu_baseline(workload: str, frames: int = 3) -> dict:
-    """Times the reference's own std::thread TileRenderer (oracle/_ref) — or the oracle port — on the
-    host cores of this box, same scene/config, threadCount = 0 (all cores)."""
+def kernel_source_hash() -> str:
+    """Identifies the kernels a PMC pass was taken on: profiles/pmc_traffic.json entries carry it, and a bench run on
+    different sources flags its counters as stale."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for rel in ("minecraftskin_raytracer_amd/csrc/render_kernels.hip", "minecraftskin_raytracer_amd/csrc/rt_core.h",
+                "minecraftskin_raytracer_amd/csrc/kernels.h", "minecraftskin_raytracer_amd/csrc/flat_scene.h", "include/mcrt_detmath.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def cpu_baseline(workload: str, gpu_frame=None, frames: int = 3, budget_s: float = 30.0) -> dict:
+    """Times the reference's own std::thread TileRenderer (oracle/_ref) — or the oracle port — on the host cores of
+    this box, same scene/config, threadCount = 0 (all cores), and compares what it rendered with the GPU frame
+    (north_star's parity sentence at full size, with this host's libm).  Frames the CPU cannot render whole within
+    the budget are timed on a cyclic sample of their tile rows (every k-th row, the reference's renderTile on the
+    same thread pool) and scaled by rows / sampled rows — stated in `sample`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
     import minecraftskin_raytracer_amd as M
@@ -82,24 +100,105 @@ def cpu_baseline(workload: str, frames: int = 3) -> dict:
     kind = "reference" if oraclelib.Reference.available() else "port"
     lib = oraclelib.Reference() if kind == "reference" else oraclelib.Oracle()
     sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
+    tiles_y = (h + cfg.tileSize - 1) // cfg.tileSize
+    # ~7 M samples/s on this class of host at the metric frame (8.3 M samples in 1.1 s); AO multiplies the work per hit
+    samples = w * h * max(cfg.samplesPerPixel, 1) * (3 if cfg.aoEnabled else 1)
+    step = max(1, int(round(samples / (7.0e6 * budget_s / 2))))
+    step = min(step, max(1, tiles_y // 4))  # at least four sampled rows
     times = []
-    budget_s = 30.0
     t_all = time.perf_counter()
-    for _ in range(frames):
+    if step == 1:
+        for _ in range(frames):
+            t0 = time.perf_counter()
+            img = lib.render(sd.ptr, cfg)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > budget_s:
+                break
+        med = statistics.median(times)
+        rows = list(range(tiles_y))
+        sample = f"{len(times)} full frame(s) of {workload}, median; threadCount=0 (std::thread pool over all host cores)"
+    else:
+        first = step // 2
+        rows = list(range(first, tiles_y, step))
+        img = np.zeros((h, w, 4), np.float32)
         t0 = time.perf_counter()
-        lib.render(sd.ptr, cfg)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > budget_s:
-            break
-    med = statistics.median(times)
-    return {
+        lib.render_rows(sd.ptr, cfg, first, step, img)
+        part = time.perf_counter() - t0
+        times.append(part)
+        med = part * tiles_y / len(rows)
+        sample = (f"{len(rows)} of {tiles_y} tile rows of {workload} (rows {first}, {first + step}, ...: every {step}th), rendered once by "
+                  f"renderTile on the same thread pool in {part:.2f} s and scaled by {tiles_y}/{len(rows)}; threadCount=0")
+    out = {
         "value": round(w * h / med / 1e6, 4),
         "unit": "Mpixels/s",
         "ms_per_frame": round(med * 1e3, 2),
         "cores": os.cpu_count(),
         "kind": kind,
-        "sample": f"{len(times)} full frame(s) of {workload}, median; threadCount=0 (std::thread pool over all host cores)",
+        "sample": sample,
     }
+    if gpu_frame is not None:
+        T = cfg.tileSize
+        px = np.concatenate([np.arange(r * T, min(h, (r + 1) * T)) for r in rows])
+        a, b = img[px], gpu_frame[px]
+        out["frame_equals_gpu"] = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+        out["rgba8_equals_gpu"] = bool(np.array_equal(M.quantize_rgba8(a), M.quantize_rgba8(b)))
+        out["compared_pixels"] = int(a.shape[0] * a.shape[1])
+        if not out["frame_equals_gpu"]:
+            out["differing_floats"] = int((a.view(np.uint32) != b.view(np.uint32)).sum())
+            out["max_abs_diff"] = float(np.nanmax(np.abs(a - b)))
+    return out
+
+
+COLD_CALL = r"""
+import json, sys, time
+sys.path.insert(0, {root!r})
+t0 = time.perf_counter()
+import numpy as np
+import minecraftskin_raytracer_amd as M
+sys.path.insert(0, {root!r})
+import bench
+cfg, skin, pose = bench.workload_config(M, {workload!r})
+sd = M.MeshBuilder.buildScene(M.synthetic_skin(skin), M.getBuiltinPoses()[pose])
+t1 = time.perf_counter()
+M.TileRenderer.render(sd, cfg)
+t2 = time.perf_counter()
+err = M.TileRenderer.lastErrors()
+M.TileRenderer.render(sd, cfg)
+t3 = time.perf_counter()
+print(json.dumps({{"first_ms": round((t2 - t1) * 1e3, 2), "second_ms": round((t3 - t2) * 1e3, 3), "import_and_scene_ms": round((t1 - t0) * 1e3, 1), "errors": err}}))
+"""
+
+
+def cold_call(workload: str):
+    """The first TileRenderer::render() of a fresh process (HIP start-up, code load, workspace allocation, seed table):
+    what one button press of the reference GUI pays once."""
+    import subprocess
+
+    try:
+        p = subprocess.run([sys.executable, "-c", COLD_CALL.format(root=ROOT, workload=workload)], capture_output=True, text=True, timeout=300)
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
+def cpp_dropin(cfg) -> dict:
+    """The C++ drop-in (csrc/host/tile_renderer_hip.cpp behind the reference's TileRenderer interface) timed by its own
+    binary: a reference-shaped Scene in, a fresh Image out per call (tools/micro/dropin_time.cpp)."""
+    import subprocess
+    import tempfile
+
+    pkg = os.path.join(ROOT, "minecraftskin_raytracer_amd")
+    host = os.path.join(pkg, "csrc", "host")
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            exe = os.path.join(tmp, "dropin_time")
+            subprocess.check_call(["g++", "-std=c++17", "-O2", f"-I{ROOT}/include", f"-I{host}", os.path.join(ROOT, "tools", "micro", "dropin_time.cpp"),
+                                   os.path.join(host, "tile_renderer_hip.cpp"), f"-L{pkg}", "-lmcrt", f"-Wl,-rpath,{pkg}", "-o", exe],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            p = subprocess.run([exe, str(cfg.width), str(cfg.height), str(cfg.maxBounces), str(cfg.samplesPerPixel), "12"], capture_output=True, text=True, timeout=300)
+            return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 def main() -> None:
@@ -109,6 +208,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="1080p_b4_spp4_S64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-host", action="store_true", help="skip the cold-process call and the C++ drop-in binary (render_call keeps its medians)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 logic where RCCL cannot run (gathers through host memory)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -266,20 +366,26 @@ def main() -> None:
     pipeline_ms = scene.time_render_device(cfg, target.data_ptr(), max(5, min(args.steps, 50)), first, stepn, layout, stream)
     torch.cuda.synchronize()
 
-    # wall time of one TileRenderer::render() call through the C ABI, host buffer in, host buffer out
+    # wall time of one TileRenderer::render() call — host scene in, a fresh host Image out
     render_call = None
     if world == 1 and rank == 0:
+        def timed(calls: int, **kw):
+            walls, splits = [], []
+            for i in range(2 + calls):
+                t0 = time.perf_counter()
+                M.TileRenderer.render(sd, cfg, **kw)
+                dt = (time.perf_counter() - t0) * 1e3
+                if M.TileRenderer.lastErrors():
+                    raise SystemExit(f"render failed: {M.TileRenderer.lastErrors()}")
+                if i >= 2:
+                    walls.append(dt)
+                    splits.append(M.TileRenderer.lastTimings())
+            return walls, splits
+
+        n_calls = max(10, min(args.steps, 20))
+        walls, splits = timed(n_calls)  # out=None: a new Image(W, H) = (0,0,0,1) per call, inside the timed region
         host = np.zeros((h, w, 4), np.float32)
-        walls, splits = [], []
-        for i in range(2 + max(10, min(args.steps, 20))):
-            t0 = time.perf_counter()
-            M.TileRenderer.render(sd, cfg, out=host)
-            dt = (time.perf_counter() - t0) * 1e3
-            if M.TileRenderer.lastErrors():
-                raise SystemExit(f"render failed: {M.TileRenderer.lastErrors()}")
-            if i >= 2:
-                walls.append(dt)
-                splits.append(M.TileRenderer.lastTimings())
+        reused, _ = timed(n_calls, out=host)
         med = statistics.median(walls)
         render_call = {
             "ms": round(med, 4),
@@ -287,10 +393,15 @@ def main() -> None:
             "calls": len(walls),
             "min_ms": round(min(walls), 4),
             "split_ms": {k: round(statistics.median(t[k] for t in splits), 4) for k in splits[0]},
-            "what": "median wall time of mcrt_render (the TileRenderer::render drop-in) into a caller-owned host frame: scene flatten + "
-                    "upload + kernels + row-group downloads overlapping the render + progress bookkeeping; the Python wrapper's own "
-                    "Image allocation is outside (a reused buffer)",
+            "reused_buffer_ms": round(statistics.median(reused), 4),
+            "what": "median wall time of TileRenderer.render (mcrt_render behind it) returning a FRESH Image per call, as the reference's call "
+                    "site gets one: Image(W,H) allocation and (0,0,0,1) fill + scene flatten + upload + kernels + rows through the pinned ring "
+                    "into the new pages + progress bookkeeping; reused_buffer_ms = the same call into one caller-owned buffer; split_ms = the "
+                    "library's own split of the C call (mcrt_last_timings)",
         }
+        if not args.quick_host:
+            render_call["cold_process"] = cold_call(args.workload)
+            render_call["cpp_dropin"] = cpp_dropin(cfg)
 
     check = None
     if args.check and rank == 0:
@@ -318,6 +429,8 @@ def main() -> None:
                 pmc = {}
         traffic = pmc.get("hbm_bytes")
         valu = pmc.get("valu_wave_instructions")
+        src_hash = kernel_source_hash()
+        pmc_stale = bool(pmc) and pmc.get("source_hash") != src_hash  # the counters were taken on other kernel sources
         roof = {
             "bound": "hbm",
             "achieved": round(achieved, 2),
@@ -327,6 +440,7 @@ def main() -> None:
             "traffic": traffic,
             "kernel": "one frame's whole pipeline on one stream (kernel.pipeline_ms; the per-kernel split is in " + str(pmc.get("profile", "profiles/")) + ")",
             "algorithmic_bytes": algo_bytes,
+            "counters": {"from": pmc.get("profile"), "source_hash": pmc.get("source_hash"), "this_build": src_hash, "stale": pmc_stale} if pmc else None,
             "note": "algorithmic bytes = 16 B x output pixels of the frame; the path is VALU/latency-bound by construction (DESIGN.md), "
                     "so the HBM fraction is << 1 %: the VALU figures are the ones that describe kernel quality",
         }
@@ -356,8 +470,9 @@ def main() -> None:
                 "workload": f"{w}x{h}, {bounces} bounces, {spp} spp, 1 light, synthetic 64x{64 if skin == 'S64' else 32} skin ({skin}), pose {pose}, soft shadows 8, tile 32"
                             + (", AO 16, DOF aperture 0.3 (reference GUI defaults)" if args.workload == "gui_defaults" else ""),
                 "name": args.workload,
-                "value_is": f"device throughput, {F} frame(s) in flight, scene and frame resident in HBM; latency_ms = one frame at a time; "
-                            "render_call.ms = one host-to-host TileRenderer::render call (SURVEY 8d)",
+                "value_is": f"device throughput, {F} frame(s) in flight, scene and frame resident in HBM (the bench contract's `value`: inputs "
+                            "resident, PCIe excluded); latency_ms = one frame at a time on the device; render_call.ms = SURVEY 8(d)'s t, one "
+                            "host-to-host TileRenderer::render call returning a fresh Image (the PCIe-inclusive figure, never `value`)",
                 "parallelism": "single GPU" if world == 1 else f"cyclic tile rows over {world} GPUs + RCCL gather to rank 0 (overlapped)",
                 "frames_in_flight": F,
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
@@ -365,8 +480,8 @@ def main() -> None:
             "latency_ms": round(latency_ms, 4),
             "latency_mpixels_per_s": round(w * h / latency_ms / 1e3, 2),
             "kernel": {"pipeline_ms": round(pipeline_ms, 4),
-                       "note": "hipEvents on the launch stream around one frame's whole pipeline on one stream (plan_tiles, primary, bounce, chase, "
-                               "light_samples, shadow, shade, resolve)"},
+                       "note": "hipEvents on the launch stream around one frame's whole pipeline on one stream (counter memset, plan_tiles, "
+                               "primary, chase, [ao,] lit, resolve)"},
             "roofline": roof,
         }
         if render_call is not None:
@@ -375,7 +490,7 @@ def main() -> None:
             line["check_assembled_frame_equals_single_gpu_render"] = check
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.workload)
+                line["cpu_baseline"] = cpu_baseline(args.workload, gpu_frame=frames[0].cpu().numpy())
             except Exception as exc:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)

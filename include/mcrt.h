@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define MCRT_ABI_VERSION 2 /* 2: mcrt_render_multi, MCRT_DEVICE_ALL; mcrt_time_render_device lost its second output */
+#define MCRT_ABI_VERSION 3 /* 2: mcrt_render_multi, MCRT_DEVICE_ALL; mcrt_time_render_device lost its second output
+                            * 3: mcrt_render_rgba8, mcrt_render_rect, mcrt_parallel_copy */
 
 /* error codes (0 = ok) */
 #define MCRT_OK 0
@@ -149,11 +150,24 @@ int mcrt_render(const mcrt_scene_desc* scene, const mcrt_config* cfg, float* out
 int mcrt_render_multi(const mcrt_scene_desc* scene, const mcrt_config* cfg, float* out_rgba,
                       mcrt_progress_fn progress, void* user, const int* devices, int n_devices, int gather);
 
+/* The same render delivering the RGBA8 plane — `(uint8_t)(clamp(c,0,1)*255.0f+0.5f)` per channel, quantised in the
+ * kernels' epilogue exactly like ImageWriter::writePNG / Image::toRGBA8 (image_writer.cpp:18-22, image.cpp:31-36) —
+ * into out_rgba8 (width*height*4 bytes): 4 B per pixel on every link (PCIe, and xGMI when gather = 1) instead of 16.
+ * devices / n_devices / gather as for mcrt_render_multi (one device: pass its index, n_devices = 1). */
+int mcrt_render_rgba8(const mcrt_scene_desc* scene, const mcrt_config* cfg, uint8_t* out_rgba8, mcrt_progress_fn progress,
+                      void* user, const int* devices, int n_devices, int gather);
+
 /* TileRenderer::renderTile (tile_renderer.cpp:71-127): renders the one tile with row-major index
  * tile_index (generateTiles order) and writes its pixels into frame_rgba, a full width*height
  * float4 frame owned by the caller; all other pixels are left untouched. */
 int mcrt_render_tile(const mcrt_scene_desc* scene, const mcrt_config* cfg, int tile_index,
                      float* frame_rgba, int device);
+/* The same for an ARBITRARY Tile {x, y, width, height} of the frame, as the reference's renderTile accepts one: the
+ * rectangle's own mt19937(tile.y * width + tile.x), its pixels in the rectangle's row-major order, cfg->tile_size not
+ * read (tile_renderer.cpp:71-127).  An empty rectangle renders nothing; one that reaches outside the frame (the
+ * reference would write out of bounds) → MCRT_ERR_INVALID.  A rectangle is one tile on the device — one RNG stream —
+ * so a very large one renders correctly but far slower than mcrt_render of the same pixels. */
+int mcrt_render_rect(const mcrt_scene_desc* scene, const mcrt_config* cfg, const mcrt_tile* tile, float* frame_rgba, int device);
 
 /* ---- render: resident scene, device buffers (bench / multi-GPU path) --------------------- */
 typedef struct mcrt_scene mcrt_scene; /* flattened scene resident in HBM on one device */
@@ -224,6 +238,12 @@ int mcrt_assemble_frame_device(const mcrt_config* cfg, int world, const float* d
  * (/root/reference/src/output/image_writer.cpp:18-22 ≡ src/skin/image.cpp:31-36). */
 int mcrt_quantize_rgba8_device(const float* d_rgba, uint8_t* d_out, size_t n_pixels, void* stream);
 void mcrt_quantize_rgba8(const float* rgba, uint8_t* out, size_t n_pixels);
+/* Host utility of the host-buffer paths: dst[0 .. bytes) = src[0 .. bytes), split over the library's copy threads
+ * (MCRT_COPY_THREADS, default 8) and the calling thread.  mcrt_render lands the frame's rows in a pinned ring and
+ * copies each landed piece into the caller's frame with it — a frame buffer the HIP runtime has never seen (the
+ * reference's call site gets a fresh Image per call) would otherwise be pinned page by page first.  May be called
+ * from several threads. */
+void mcrt_parallel_copy(void* dst, const void* src, size_t bytes);
 
 /* ---- PNG hand-off (the step after the path: ImageWriter::writePNG, image_writer.cpp:6-28) -------- */
 /* Writes an 8-bit RGBA PNG (colour type 6, no interlace, filter 0, zlib *stored* blocks: no
@@ -235,8 +255,8 @@ int mcrt_write_png_rgba8(const char* path, const uint8_t* rgba, int width, int h
 size_t mcrt_encode_png_rgba8(const uint8_t* rgba, int width, int height, uint8_t* out, size_t capacity);
 /* Quantise a float RGBA image exactly like ImageWriter::writePNG and write it. */
 int mcrt_write_png_f32(const char* path, const float* rgba, int width, int height);
-/* TileRenderer::render + ImageWriter::writePNG in one call: render on `device`, quantise in the
- * kernel epilogue, copy 4 B/pixel back, write the file.  Invalid frame sizes write nothing and
+/* TileRenderer::render + ImageWriter::writePNG in one call: render on `device` (an index, or MCRT_DEVICE_ALL), quantise
+ * in the kernel epilogue, copy 4 B/pixel back (mcrt_render_rgba8), write the file.  Invalid frame sizes write nothing and
  * return MCRT_ERR_INVALID (writePNG rejects empty images, image_writer.cpp:7-9). */
 int mcrt_render_png(const mcrt_scene_desc* scene, const mcrt_config* cfg, const char* path, int device);
 
@@ -305,7 +325,8 @@ int mcrt_probe_detmath_range(int device, int op, uint32_t lo_bits, uint32_t hi_b
 /* div_frame — the frame-constant division of the sample coordinates (rt_core.h) — against the general division on the
  * device, for the integer divisors d_first .. d_first + d_count - 1 and every float a sample coordinate can take
  * (0 and 2^-33 .. d + 1); mode 1 checks the form with a second correction, mode 2 the uncorrected product (the probe's
- * own check); mode 3: rt::sqrt_pos against sqrtf for 0 and every float from 2^-96 to infinity.  tools/gpu_verify_div.py */
+ * own check); mode 3: rt::sqrt_pos against sqrtf for 0 and every float from 2^-96 to infinity; mode 4: the device's 1.0f / d
+ * against the host's (the reciprocals the probe — like the render kernels — uses are the HOST's).  tools/gpu_verify_div.py */
 int mcrt_probe_div_const(int device, uint32_t d_first, uint32_t d_count, int mode, uint64_t* mismatches, uint32_t* a_failing_divisor);
 
 #ifdef __cplusplus

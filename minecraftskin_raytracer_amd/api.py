@@ -111,6 +111,29 @@ def getBuiltinPoses() -> List[np.ndarray]:
     return out
 
 
+def _devices(device):
+    """``device`` argument of the render entry points → (one index, None) or (None, list of indices; [] = every visible
+    device).  Accepts any integer type (numpy, torch device indices), ``"all"`` / ``-1``, or a sequence of indices."""
+    import operator
+
+    if isinstance(device, str):
+        if device != "all":
+            raise ValueError("device must be an index, 'all' or a sequence of indices")
+        return None, []
+    try:
+        d = operator.index(device)
+    except TypeError:
+        devs = [operator.index(x) for x in device]
+        if any(x < 0 for x in devs):
+            raise ValueError("device indices must be >= 0")
+        return None, devs
+    if d == -1:
+        return None, []
+    if d < 0:
+        raise ValueError("device must be >= 0, or -1 / 'all' for every visible device")
+    return d, None
+
+
 class TileRenderer:
     """raytracer/tile_renderer.h:16-47."""
 
@@ -148,20 +171,53 @@ class TileRenderer:
         if w == 0 or h == 0 or config.tileSize <= 0:
             return out
         cb = abi.PROGRESS_FN((lambda done, total, _u: progressCallback(done, total))) if progressCallback else C.cast(None, abi.PROGRESS_FN)
-        if isinstance(device, str):
-            if device != "all":
-                raise ValueError("device must be an index, 'all' or a sequence of indices")
-            device = -1
-        if isinstance(device, int) and device >= 0:
-            rc = lib.mcrt_render(d.ptr, C.byref(c), abi.fptr(out), cb, None, device)
+        one, devs = _devices(device)
+        if one is not None:
+            rc = lib.mcrt_render(d.ptr, C.byref(c), abi.fptr(out), cb, None, one)
         else:
-            devs = [] if isinstance(device, int) else [int(x) for x in device]
             arr = (C.c_int * max(len(devs), 1))(*devs)
             rc = lib.mcrt_render_multi(d.ptr, C.byref(c), abi.fptr(out), cb, None, arr if devs else None, len(devs), 1 if gather else 0)
         if rc != 0:
             TileRenderer._errors = [(-1, lib.mcrt_last_error().decode("utf-8", "replace"))]
             out[...] = 0.0
             out[..., 3] = 1.0
+        return out
+
+    @staticmethod
+    def renderTile(tile: Tuple[int, int, int, int], scene, config: Config, output: np.ndarray, device: int = 0) -> None:
+        """TileRenderer::renderTile (tile_renderer.cpp:71-127): one Tile ``(x, y, width, height)`` — any rectangle of the
+        frame, its own mt19937(y * width + x) — into ``output`` ((H, W, 4) float32), every other pixel untouched.
+        Failures are recorded in ``lastErrors()``."""
+        if output.shape != (config.height, config.width, 4) or output.dtype != np.float32 or not output.flags["C_CONTIGUOUS"]:
+            raise ValueError("output must be a C-contiguous (height, width, 4) float32 array")
+        c = config.to_c()
+        t = abi.McrtTile(*[int(v) for v in tile])
+        lib = load()
+        if lib.mcrt_render_rect(_as_desc(scene).ptr, C.byref(c), C.byref(t), abi.fptr(output), int(device)) != 0:
+            TileRenderer._errors.append((-1, lib.mcrt_last_error().decode("utf-8", "replace")))
+
+    @staticmethod
+    def renderRGBA8(scene, config: Config, device=0, gather: bool = False) -> np.ndarray:
+        """The frame as the RGBA8 plane ImageWriter::writePNG would encode ((H, W, 4) uint8), quantised in the kernels'
+        epilogue: 4 B per pixel over PCIe / xGMI instead of 16 (mcrt_render_rgba8).  ``device`` as for ``render``."""
+        lib = load()
+        c = config.to_c()
+        w, h = max(config.width, 0), max(config.height, 0)
+        out = np.zeros((h, w, 4), np.uint8)
+        out[..., 3] = 255
+        TileRenderer._errors = []
+        if w == 0 or h == 0 or config.tileSize <= 0:
+            return out
+        one, devs = _devices(device)
+        if one is not None:
+            devs = [one]
+        arr = (C.c_int * max(len(devs), 1))(*devs)
+        rc = lib.mcrt_render_rgba8(_as_desc(scene).ptr, C.byref(c), out.ctypes.data_as(C.POINTER(C.c_uint8)), C.cast(None, abi.PROGRESS_FN), None,
+                                   arr if devs else None, len(devs), 1 if gather else 0)
+        if rc != 0:
+            TileRenderer._errors = [(-1, lib.mcrt_last_error().decode("utf-8", "replace"))]
+            out[...] = 0
+            out[..., 3] = 255
         return out
 
     @staticmethod
@@ -328,10 +384,13 @@ def probe_detmath_range(op: int, lo_bits: int, hi_bits: int, y0: float = 0.0, de
     return int(bad.value)
 
 
-def probe_div_const(d_first: int, d_count: int, two_corrections: bool = False, device: int = 0):
-    """(mismatches, a failing divisor or 0): rt::div_frame against the general division, exhaustively (mcrt.h)."""
+def probe_div_const(d_first: int, d_count: int, two_corrections: bool = False, device: int = 0, mode: Optional[int] = None):
+    """(mismatches, a failing divisor or 0): rt::div_frame against the general division, exhaustively (mcrt.h).
+    ``mode``: 0 the adopted form, 1 with a second correction, 2 the uncorrected product (the probe's own check: must
+    mismatch), 3 rt::sqrt_pos against sqrtf, 4 the device's 1.0f / d against the host's reciprocal the kernels are given."""
     bad, which = C.c_uint64(), C.c_uint32()
-    check(load().mcrt_probe_div_const(device, d_first, d_count, 1 if two_corrections else 0, C.byref(bad), C.byref(which)))
+    m = (1 if two_corrections else 0) if mode is None else int(mode)
+    check(load().mcrt_probe_div_const(device, d_first, d_count, m, C.byref(bad), C.byref(which)))
     return int(bad.value), int(which.value)
 
 

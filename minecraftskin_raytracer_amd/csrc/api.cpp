@@ -2,6 +2,7 @@
 //
 // There is deliberately no CPU fallback anywhere in this file: every render / probe entry point
 // needs a HIP device and fails with MCRT_ERR_NO_DEVICE / MCRT_ERR_HIP otherwise.
+#include "copy_pool.h"
 #include "flatten.h"
 #include "kernels.h"
 #include "mcrt.h"
@@ -96,14 +97,18 @@ constexpr int kMaxLanes = 4;
 struct RngKey {
     const void* ptr = nullptr;
     int width = 0, tile_size = 0, first = 0, step = 0, tiles_x = 0, owned_rows = 0;
+    int rect[4] = {0, 0, 0, 0};
     bool operator==(const RngKey& o) const {
         return ptr == o.ptr && width == o.width && tile_size == o.tile_size && first == o.first && step == o.step && tiles_x == o.tiles_x &&
-               owned_rows == o.owned_rows;
+               owned_rows == o.owned_rows && rect[0] == o.rect[0] && rect[1] == o.rect[1] && rect[2] == o.rect[2] && rect[3] == o.rect[3];
     }
 };
 struct Lane {
     hipStream_t stream = nullptr;  // owned; unused for lane 0
     hipEvent_t done = nullptr;
+    // side branch of a lone frame: the background tiles render beside the chain of the tiles that hold the figure
+    hipStream_t side = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
     DeviceBuffer tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queues[5], texel_refs, targets, cand, lit[2], stack, counters, hit_rng;
     RngKey rng_key;               // which tile seeds tile_rng holds (ptr == nullptr: none)
@@ -118,6 +123,7 @@ struct mcrt_scene {
     DeviceBuffer blob;
     Lane lanes[kMaxLanes];
     int forced_lanes = 0;  // mcrt_scene_set_lanes: 0 = automatic
+    bool one_shot = false;  // a host-buffer render (mcrt_render & co): one frame at a time on one stream
     size_t budget = 0;     // current workspace budget (0 = workspace_budget()); halved when the device is short of memory
     // recorded launch sequences of recent renders (hipGraph), replayed when the parameters repeat
     struct Recorded {
@@ -150,6 +156,10 @@ struct mcrt_scene {
     // back): no pin / unpin of a few KB of pageable memory per call
     void* staging = nullptr;
     size_t staging_bytes = 0;
+    // pinned ring the rows of a host-buffer render land in before worker threads copy them into the caller's frame
+    // (kRingSlots pieces of kRingPiece bytes; see download_staged)
+    void* ring = nullptr;
+    hipEvent_t ring_ev[16] = {};
     const uint32_t* seed_table = nullptr;  // the device's table of mt19937 seeding results (kernels.h), or NULL
     bool holds_seed_table = false;
 };
@@ -157,14 +167,21 @@ struct mcrt_scene {
 namespace {
 
 // workspace budget of a render (bytes, all lanes together); MCRT_WORKSPACE_MB overrides (tests use a
-// small value to force multi-batch renders).  The default is a third of the MI355X's 288 GB: the
-// workspace is sized for the worst case of every sample hitting (~300 B per sample), buffers only
-// ever grow to what a frame needs, and a frame cut into few large batches is much faster than many
-// small ones (4K / 8 bounces / 16 spp: 9.7 ms with 4 GiB, 6.1 ms in one batch).
-size_t workspace_budget() {  // read per scene: tests switch it between renders
+// small value to force multi-batch renders).  By default a third of the CURRENT device's memory (96 GB of the
+// MI355X's 288), never more than 80 % of what is free right now: the workspace is sized for the worst case of every
+// sample hitting (~300 B per sample), buffers only ever grow to what a frame needs, and a frame cut into few large
+// batches is much faster than many small ones (4K / 8 bounces / 16 spp: 9.7 ms with 4 GiB, 6.1 ms in one batch).
+size_t workspace_budget() {  // read per scene (current device = the scene's): tests switch it between renders
     const char* e = std::getenv("MCRT_WORKSPACE_MB");
     const long long mb = e ? std::atoll(e) : 0;
-    return static_cast<size_t>(mb > 0 ? mb : 96 * 1024) << 20;
+    if (mb > 0) return static_cast<size_t>(mb) << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) {
+        (void)hipGetLastError();
+        return static_cast<size_t>(8) << 30;
+    }
+    const size_t third = total_b / 3, room = free_b / 5 * 4;
+    return std::max<size_t>(static_cast<size_t>(256) << 20, std::min(third, room));
 }
 
 // lanes for a shard: enough work per lane that the extra launches pay (MCRT_LANES forces a count)
@@ -241,10 +258,20 @@ void touched_tiles_per_row(const mcrt_scene* sc, const mcrt_config& cfg, const S
     }
 }
 
+// development knobs: -1 = the library's choice, 0 / 1 forced
+int env_tristate(const char* name) {
+    const char* e = std::getenv(name);
+    if (!e || !e[0]) return -1;
+    return std::atoi(e) != 0 ? 1 : 0;
+}
+// A handle whose caller has not said that it keeps several frames in flight itself (mcrt_scene_set_lanes(n >= 1)) renders
+// ONE frame at a time: what counts is the length of the frame's dependent chain, not the instruction count.
+bool lone_frame(const mcrt_scene* s) { return s->forced_lanes == 0 || s->one_shot; }
+
 // fill RenderParams for lane `li` of `n_lanes` over the shard (first, step) + make sure its
 // workspace exists (allocation only when it has to grow)
 int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int first, int step, int layout, float* d_out,
-            uint8_t* d_out8, RenderParams& p, std::vector<int>* row_touched_out = nullptr) {
+            uint8_t* d_out8, RenderParams& p, std::vector<int>* row_touched_out = nullptr, const mcrt_tile* rect = nullptr) {
     Lane* s = &sc->lanes[li];
     std::memset(&p, 0, sizeof p);
     p.scene = static_cast<const uint8_t*>(sc->blob.ptr);
@@ -255,6 +282,13 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
             return !(e && e[0] == '0');
         }();
         p.bundle_decisions = decisions ? 1 : 0;
+    }
+    {
+        static const int plan_wg = env_tristate("MCRT_PLAN_WG"), fold = env_tristate("MCRT_FOLD_CHASE"), raygen = env_tristate("MCRT_LIT_RAYGEN");
+        // measured on the MI355X (profiles/r03_*): none of the three pays at the metric frame — the defaults are off
+        p.plan_wg = plan_wg < 0 ? 0 : plan_wg;
+        p.fold_chase = fold < 0 ? 0 : fold;
+        p.lit_raygen = raygen < 0 ? 0 : raygen;
     }
     p.cfg = *cfg;
     if (cfg->width > 0 && cfg->height > 0) {
@@ -269,6 +303,11 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     p.shard = make_shard(*cfg, first + li * step, step * n_lanes);
     p.shard.pack_first = li;
     p.shard.pack_step = n_lanes;
+    if (rect) {  // one tile: the rectangle (renderTile); the output holds its pixel rows, packed
+        p.rect_x = rect->x, p.rect_y = rect->y, p.rect_w = rect->width, p.rect_h = rect->height;
+        p.shard.first = 0, p.shard.step = 1, p.shard.tiles_x = 1, p.shard.tiles_y = 1, p.shard.owned_rows = 1;
+        p.shard.pack_first = 0, p.shard.pack_step = 1;
+    }
     p.layout = layout;
     p.out = d_out;
     p.out8 = d_out8;
@@ -283,7 +322,10 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     // lane's buffers are re-planned, instead of failing the render.
     WorkspaceBytes w{};
     std::vector<int> row_touched;
-    touched_tiles_per_row(sc, *cfg, p.shard, row_touched);
+    if (rect)
+        row_touched.assign(1, 1);  // the rectangle counts as touched (plan_tiles decides on the device)
+    else
+        touched_tiles_per_row(sc, *cfg, p.shard, row_touched);
     for (;;) {
         if (!sc->budget) sc->budget = workspace_budget();
         w = plan_workspace(p, sc->budget / static_cast<size_t>(n_lanes), row_touched.empty() ? nullptr : row_touched.data());
@@ -377,6 +419,7 @@ RngKey rng_key_of(const RenderParams& p) {
     k.ptr = p.tile_rng;
     k.width = p.cfg.width, k.tile_size = p.cfg.tile_size;
     k.first = p.shard.first, k.step = p.shard.step, k.tiles_x = p.shard.tiles_x, k.owned_rows = p.shard.owned_rows;
+    k.rect[0] = p.rect_x, k.rect[1] = p.rect_y, k.rect[2] = p.rect_w, k.rect[3] = p.rect_h;
     return k;
 }
 
@@ -398,8 +441,8 @@ constexpr int kMaxBounces = 4000;
 // that depends on data lives on the device), so it is recorded once through stream capture on a private
 // stream, lanes included, and replayed with a single hipGraphLaunch: ~75 us of launch calls per render
 // become one.
-int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream, bool may_record) {
-    if (!graphs_enabled() || !may_record) return launch_lanes(s, p, n_lanes, stream);
+int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream, bool may_record, const LaunchMarks* marks) {
+    if (!graphs_enabled() || !may_record) return launch_lanes(s, p, n_lanes, stream, marks);
     ++s->use_clock;
     mcrt_scene::Recorded* slot = nullptr;
     for (auto& r : s->recorded)
@@ -430,11 +473,11 @@ int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStrea
             slot = victim;
         }
         slot->last_use = s->use_clock;
-        if (++slot->sightings < kRecordAt) return launch_lanes(s, p, n_lanes, stream);
+        if (++slot->sightings < kRecordAt) return launch_lanes(s, p, n_lanes, stream, marks);
         if (!s->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
         hipError_t e = hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            const int rc = launch_lanes(s, p, n_lanes, s->capture_stream);
+            const int rc = launch_lanes(s, p, n_lanes, s->capture_stream, marks);
             hipGraph_t g = nullptr;
             e = hipStreamEndCapture(s->capture_stream, &g);
             if (rc == MCRT_OK && e == hipSuccess && g) {
@@ -453,7 +496,7 @@ int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStrea
         if (!slot->exec) {  // recording failed: forget it and launch directly
             (void)hipGetLastError();
             slot->n_lanes = 0;
-            return launch_lanes(s, p, n_lanes, stream);
+            return launch_lanes(s, p, n_lanes, stream, marks);
         }
     }
     slot->last_use = s->use_clock;
@@ -479,8 +522,9 @@ hipEvent_t next_mark(mcrt_scene* s) {  // pooled per scene shell
 // launches also record events that tell when which tile rows are final, *groups lists them in
 // completion order (direct launches, no graph replay: the events are this call's own).
 int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, int layout, float* d_out, uint8_t* d_out8,
-                   hipStream_t stream, bool may_record = true, std::vector<RowGroup>* groups = nullptr) {
-    const Shard whole = make_shard(*cfg, first, step);
+                   hipStream_t stream, bool may_record = true, std::vector<RowGroup>* groups = nullptr, const mcrt_tile* rect = nullptr) {
+    Shard whole = make_shard(*cfg, first, step);
+    if (rect) whole.owned_rows = 1;
     if (whole.owned_rows <= 0) return MCRT_OK;
     if (cfg->max_bounces > kMaxBounces) return fail(MCRT_ERR_INVALID, "max_bounces above 4000 is not supported (one stack slot per level and sample)");
     const int n_lanes = lane_count(s, *cfg, whole);
@@ -488,7 +532,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     std::memset(p, 0, sizeof p);
     std::vector<int> row_touched[kMaxLanes];
     for (int li = 0; li < n_lanes; ++li) {
-        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li], groups ? &row_touched[li] : nullptr);
+        int rc = prepare(s, li, n_lanes, cfg, first, step, layout, d_out, d_out8, p[li], groups ? &row_touched[li] : nullptr, rect);
         if (rc != MCRT_OK) return rc;
         Lane& ln = s->lanes[li];
         if (li > 0 && !ln.stream) {
@@ -565,7 +609,26 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
         }
         return rc;
     }
-    rc = capturing ? launch_lanes(s, p, n_lanes, stream) : launch_or_replay(s, p, n_lanes, stream, may_record);
+    // a lone frame on the device path: every lane's background tiles on a side branch (kernels.h: LaunchMarks)
+    LaunchMarks side_marks[kMaxLanes];
+    bool split = false;
+    {
+        static const int forced = env_tristate("MCRT_BG_SPLIT");
+        split = forced < 0 ? false : forced != 0;
+    }
+    for (int li = 0; li < n_lanes && split; ++li) {
+        Lane& ln = s->lanes[li];
+        if (!ln.side) {
+            HIP_TRY(hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ln.side_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ln.side_join, hipEventDisableTiming));
+        }
+        side_marks[li].side = ln.side;
+        side_marks[li].side_fork = ln.side_fork;
+        side_marks[li].side_join = ln.side_join;
+    }
+    const LaunchMarks* sm = split ? side_marks : nullptr;
+    rc = capturing ? launch_lanes(s, p, n_lanes, stream, sm) : launch_or_replay(s, p, n_lanes, stream, may_record, sm);
     if (rc == MCRT_OK && !capturing) {
         HIP_TRY(hipEventRecord(s->last_done, stream));
         s->last_stream = stream;
@@ -645,15 +708,26 @@ void free_unused_seed_tables() {  // mcrt_trim
     }
 }
 
-// keeps `s` for reuse unless it is large (MCRT_POOL_MB, default 49152 — a sixth of the MI355X's 288 GB: re-allocating
-// the tens of GB a 4K / 8K frame needs made each one-shot call of such a frame take about a second) or the
-// device already has one
+// keeps `s` for reuse unless it is large — MCRT_POOL_MB, by default a twelfth of the device's memory (24 GB of the
+// MI355X's 288: the 1080p and 4K frames of BASELINE.json stay pooled, and a host application that never calls
+// mcrt_trim() does not sit on a fifth of the card; re-allocating the tens of GB an 8K / 64 spp frame needs costs each
+// one-shot call of such a frame about a second) — or the device already has one
 bool pool_scene(mcrt_scene* s) {
-    static const size_t limit = [] {
+    static const long long forced_mb = [] {
         const char* e = std::getenv("MCRT_POOL_MB");
-        long long mb = e ? std::atoll(e) : 49152;
-        return static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
+        return e ? std::atoll(e) : -1ll;
     }();
+    size_t limit;
+    if (forced_mb >= 0) {
+        limit = static_cast<size_t>(forced_mb) << 20;
+    } else {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            total_b = 0;
+        }
+        limit = total_b / 12;
+    }
     if (workspace_bytes(s) > limit) return false;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (mcrt_scene* q : g_pool)
@@ -752,6 +826,7 @@ int create_scene_from_blob(const std::vector<uint8_t>& b, int device, mcrt_scene
         s->device = device;
     }
     s->forced_lanes = 0;
+    s->one_shot = false;
     s->budget = 0;  // a budget halved under memory pressure is not inherited
     s->have_last = false;  // a pooled shell was synchronised when its previous owner let go of it
     s->last_stream = nullptr;
@@ -832,6 +907,10 @@ void destroy_scene_now(mcrt_scene* s) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
         if (ln.done) (void)hipEventDestroy(ln.done);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
+        if (ln.side) (void)hipStreamSynchronize(ln.side);
+        if (ln.side_fork) (void)hipEventDestroy(ln.side_fork);
+        if (ln.side_join) (void)hipEventDestroy(ln.side_join);
+        if (ln.side) (void)hipStreamDestroy(ln.side);
     }
     for (auto& r : s->recorded) {
         if (r.exec) (void)hipGraphExecDestroy(r.exec);
@@ -841,6 +920,9 @@ void destroy_scene_now(mcrt_scene* s) {
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->last_done) (void)hipEventDestroy(s->last_done);
     if (s->staging) (void)hipHostFree(s->staging);
+    if (s->ring) (void)hipHostFree(s->ring);
+    for (hipEvent_t ev : s->ring_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (s->main_stream) (void)hipStreamDestroy(s->main_stream);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     for (hipEvent_t m : s->marks) (void)hipEventDestroy(m);
@@ -961,6 +1043,64 @@ int validate_config(const mcrt_config* cfg) {
     return MCRT_OK;
 }
 
+// ---- host-buffer downloads through a pinned ring ---------------------------------------------------------
+// hipMemcpyAsync into pageable memory the runtime has not seen before pins the pages first: ~2.6 ms per 33 MB
+// (tools/micro/d2h.cpp) — and the reference's call site gets a fresh Image per call (tile_renderer.cpp:141).  So the
+// rows land in a pinned ring owned by the (pooled) scene shell at PCIe rate, piece by piece, and a few worker threads
+// copy each landed piece into the caller's frame while the next pieces are still on the bus.
+constexpr size_t kRingPiece = static_cast<size_t>(4) << 20;
+constexpr int kRingSlots = 16;
+
+struct CopySpan {  // a contiguous run: device bytes → host bytes
+    const char* src;
+    char* dst;
+    size_t bytes;
+};
+// MCRT_HOST_COPY=direct: hipMemcpyAsync straight into the caller's frame (fastest when the caller renders into ONE buffer
+// again and again: the runtime keeps its pages pinned); default: through the ring
+bool host_copy_staged() {
+    static const bool v = [] {
+        const char* e = std::getenv("MCRT_HOST_COPY");
+        return !(e && std::strcmp(e, "direct") == 0);
+    }();
+    return v;
+}
+hipError_t ensure_ring(mcrt_scene* s) {
+    if (s->ring) return hipSuccess;
+    hipError_t e = hipHostMalloc(&s->ring, kRingPiece * kRingSlots, hipHostMallocDefault);
+    for (int i = 0; i < kRingSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->ring_ev[i], hipEventDisableTiming);
+    return e;
+}
+// the spans through the scene's ring on its copy stream; `parallel`: landed pieces are copied out by the pool (one rank),
+// else by the calling thread alone (one copier thread per rank already)
+hipError_t download_staged(mcrt_scene* s, const std::vector<CopySpan>& spans, bool parallel) {
+    hipError_t e = ensure_ring(s);
+    if (e != hipSuccess) return e;
+    std::vector<CopySpan> pieces;
+    for (const CopySpan& sp : spans)
+        for (size_t off = 0; off < sp.bytes; off += kRingPiece) pieces.push_back(CopySpan{sp.src + off, sp.dst + off, std::min(kRingPiece, sp.bytes - off)});
+    size_t issued = 0;
+    char* ring = static_cast<char*>(s->ring);
+    for (size_t k = 0; k < pieces.size() && e == hipSuccess; ++k) {
+        while (issued < pieces.size() && issued < k + static_cast<size_t>(kRingSlots) && e == hipSuccess) {  // keep the bus busy: up to a ring of pieces ahead
+            const int slot = static_cast<int>(issued % kRingSlots);
+            e = hipMemcpyAsync(ring + static_cast<size_t>(slot) * kRingPiece, pieces[issued].src, pieces[issued].bytes, hipMemcpyDeviceToHost, s->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(s->ring_ev[slot], s->copy_stream);
+            ++issued;
+        }
+        if (e != hipSuccess) break;
+        const int slot = static_cast<int>(k % kRingSlots);
+        e = hipEventSynchronize(s->ring_ev[slot]);
+        if (e != hipSuccess) break;
+        if (parallel)
+            parallel_copy(pieces[k].dst, ring + static_cast<size_t>(slot) * kRingPiece, pieces[k].bytes);
+        else
+            std::memcpy(pieces[k].dst, ring + static_cast<size_t>(slot) * kRingPiece, pieces[k].bytes);
+    }
+    if (e != hipSuccess) (void)hipStreamSynchronize(s->copy_stream);  // nothing of this call stays in flight
+    return e;
+}
+
 int one_shot_streams(mcrt_scene* s) {
     if (!s->main_stream) HIP_TRY(hipStreamCreateWithFlags(&s->main_stream, hipStreamNonBlocking));
     if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
@@ -977,14 +1117,45 @@ struct HostRank {
     std::vector<RowGroup> groups;
 };
 
+// Peer access between the gather root and a rank's device, both directions, once per pair and process.  false: the
+// pair cannot reach each other directly (the caller falls back to per-device downloads).
+bool peer_access(int root, int other) {
+    if (root == other) return true;
+    static std::mutex mu;
+    static std::vector<std::pair<int, int>> enabled;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& pr : enabled)
+        if (pr.first == root && pr.second == other) return true;
+    int a = 0, b = 0;
+    if (hipDeviceCanAccessPeer(&a, root, other) != hipSuccess || hipDeviceCanAccessPeer(&b, other, root) != hipSuccess || !a || !b) {
+        (void)hipGetLastError();
+        return false;
+    }
+    auto enable = [](int dev, int peer) {
+        if (hipSetDevice(dev) != hipSuccess) return false;
+        const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return false;
+        (void)hipGetLastError();
+        return true;
+    };
+    if (!enable(root, other) || !enable(other, root)) {
+        (void)hipGetLastError();
+        return false;
+    }
+    enabled.emplace_back(root, other);
+    return true;
+}
+
 // Renders the frame on the given devices — rank r of N takes tile rows r, r+N, ... (cyclic: the figure sits in
-// the middle rows) on devices[r] — and assembles it in out_rgba.
+// the middle rows) on devices[r] — and assembles it in `out`: float4 pixels (px_bytes = 16) or the RGBA8 plane
+// quantised in the kernels' epilogue (px_bytes = 4: a quarter of the bytes on every link).
 //   gather = 0: every device downloads its own rows straight into the host frame (N PCIe links in parallel,
 //               no device-to-device traffic); rows that are final early travel while the rest still renders.
-//   gather = 1: the ranks' packed rows go to devices[0] by peer copies (xGMI), one launch un-permutes them, one
-//               download brings the frame back.
-// Progress callbacks (exactly totalTiles, done = 1..total) fire on the calling thread as row groups land.
-int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_rgba, mcrt_progress_fn progress, void* user,
+//   gather = 1: the ranks' packed rows go to devices[0] by peer copies (xGMI; peer access enabled once per pair — a
+//               pair without it falls back to gather = 0); as each rank's rows arrive they are un-permuted into the
+//               frame on the root and downloaded, so progress follows the ranks as they land.
+// Progress callbacks (exactly totalTiles, done = 1..total) fire on the calling thread as rows land in `out`.
+int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, void* out, int px_bytes, mcrt_progress_fn progress, void* user,
                    const int* devices, int n_ranks, int gather) {
     const double t0 = now_ms();
     std::vector<uint8_t> blob;
@@ -993,9 +1164,14 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* o
     const Shard all = make_shard(*cfg, 0, 1);
     if (n_ranks > all.tiles_y) n_ranks = all.tiles_y;  // no more ranks than tile rows
     if (n_ranks <= 1) gather = 0;
+    for (int r = 1; r < n_ranks && gather; ++r)
+        if (!peer_access(devices[0], devices[r])) gather = 0;
     const int W = cfg->width, T = cfg->tile_size;
-    const size_t row_bytes = static_cast<size_t>(T) * W * 16;
+    const size_t px = static_cast<size_t>(px_bytes);
+    const size_t row_bytes = static_cast<size_t>(T) * W * px;
+    const size_t whole_bytes = static_cast<size_t>(W) * cfg->height * px;
     const int total_tiles = all.tiles_x * all.tiles_y;
+    char* out_bytes = static_cast<char*>(out);
     std::vector<HostRank> ranks(static_cast<size_t>(n_ranks));
     int rc = MCRT_OK;
     auto cleanup = [&](int code) {
@@ -1015,22 +1191,23 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* o
         // path (1 MB chunks, ~15 GB/s: 2.3 ms per 1080p call instead of 0.8, tools/micro/hostpath.cpp), and
         // for a host-buffer render the download, not the chain of kernels, is the longer part.
         s->forced_lanes = 1;
+        s->one_shot = true;
         rc = one_shot_streams(s);
         if (rc != MCRT_OK) break;
         const Shard mine = make_shard(*cfg, r, n_ranks);
         const bool packed = n_ranks > 1;
-        const size_t frame_bytes = packed ? static_cast<size_t>(mine.owned_rows) * row_bytes : static_cast<size_t>(W) * cfg->height * 16;
+        const size_t frame_bytes = packed ? static_cast<size_t>(mine.owned_rows) * row_bytes : whole_bytes;
         size_t want = frame_bytes;
         if (gather && r == 0)  // the root also holds every rank's packed rows and the assembled frame
-            want = static_cast<size_t>(n_ranks) * (static_cast<size_t>((all.tiles_y + n_ranks - 1) / n_ranks) * row_bytes) + static_cast<size_t>(W) * cfg->height * 16;
+            want = static_cast<size_t>(n_ranks) * (static_cast<size_t>((all.tiles_y + n_ranks - 1) / n_ranks) * row_bytes) + whole_bytes;
         hipError_t e = s->frame.reserve(want);
         if (e != hipSuccess) {
             rc = hip_fail(e, "frame allocation");
             break;
         }
         if (r == 0) (void)hipEventRecord(s->ev[0], s->main_stream);
-        rc = enqueue_render(s, cfg, r, n_ranks, packed ? MCRT_LAYOUT_PACKED : MCRT_LAYOUT_FRAME, static_cast<float*>(s->frame.ptr), nullptr,
-                            s->main_stream, /*may_record=*/false, &hr.groups);
+        rc = enqueue_render(s, cfg, r, n_ranks, packed ? MCRT_LAYOUT_PACKED : MCRT_LAYOUT_FRAME, px_bytes == 16 ? static_cast<float*>(s->frame.ptr) : nullptr,
+                            px_bytes == 4 ? static_cast<uint8_t*>(s->frame.ptr) : nullptr, s->main_stream, /*may_record=*/false, &hr.groups);
         if (rc == MCRT_OK && r == 0) (void)hipEventRecord(s->ev[3], s->main_stream);
     }
     if (rc != MCRT_OK) return cleanup(rc);
@@ -1041,34 +1218,43 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* o
         for (size_t i = 0; i < rows.size(); ++i)
             for (int x = 0; x < all.tiles_x; ++x) progress(++done_tiles, total_tiles, user);
     };
+    // device bytes → host frame for a list of tile rows; `packed_rank` >= 0: the source holds only that rank's rows, packed
+    auto spans_of = [&](const char* src0, const std::vector<int>& rows, int packed_rank) {
+        std::vector<CopySpan> spans;
+        for (size_t i = 0; i < rows.size();) {
+            size_t j = i + 1;
+            if (packed_rank < 0)  // consecutive tile rows of a frame-shaped source are one run
+                while (j < rows.size() && rows[j] == rows[j - 1] + 1) ++j;
+            size_t bytes = 0;
+            for (size_t k = i; k < j; ++k) bytes += static_cast<size_t>(tile_row_height(*cfg, rows[k])) * W * px;
+            const int row = rows[i];
+            const size_t src_off = (packed_rank < 0 ? static_cast<size_t>(row) : static_cast<size_t>((row - packed_rank) / n_ranks)) * row_bytes;
+            spans.push_back(CopySpan{src0 + src_off, out_bytes + static_cast<size_t>(row) * row_bytes, bytes});
+            i = j;
+        }
+        return spans;
+    };
+    // the spans on `s`'s copy stream: through the pinned ring (default) or straight into the caller's pages
+    auto download = [&](mcrt_scene* s, const std::vector<CopySpan>& spans, bool pool) -> hipError_t {
+        if (host_copy_staged()) return download_staged(s, spans, pool);
+        hipError_t ce = hipSuccess;
+        for (const CopySpan& sp : spans)
+            if (ce == hipSuccess) ce = hipMemcpyAsync(sp.dst, sp.src, sp.bytes, hipMemcpyDeviceToHost, s->copy_stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(s->copy_stream);
+        return ce;
+    };
     hipError_t e = hipSuccess;
     if (!gather) {
         // ---- downloads: a rank's row groups in completion order.  The host waits for a group's events, then
-        // copies on the (idle) copy stream; early groups travel while the GPU still renders the rest.  The
-        // runtime pins the caller's pages on first use and remembers them, so a caller that renders into the
-        // same buffer again gets 56 GB/s (0.6 ms for the 1080p frame; tools/micro/d2h.cpp).
+        // copies on the (idle) copy stream; early groups travel while the GPU still renders the rest.
         auto download_group = [&](int r, size_t g) -> hipError_t {
             HostRank& hr = ranks[static_cast<size_t>(r)];
             mcrt_scene* s = hr.scene;
             hipError_t ce = hipSetDevice(hr.device);
             const RowGroup& grp = hr.groups[g];
             for (size_t i = 0; i < grp.wait.size() && ce == hipSuccess; ++i) ce = hipEventSynchronize(grp.wait[i]);
-            const char* src0 = static_cast<const char*>(s->frame.ptr);
-            for (size_t i = 0; i < grp.rows.size() && ce == hipSuccess;) {
-                // a run of consecutive tile rows is one copy when the device buffer is the frame itself
-                size_t j = i + 1;
-                if (n_ranks == 1)
-                    while (j < grp.rows.size() && grp.rows[j] == grp.rows[j - 1] + 1) ++j;
-                const int row = grp.rows[i];
-                size_t bytes = 0;
-                for (size_t k = i; k < j; ++k) bytes += static_cast<size_t>(tile_row_height(*cfg, grp.rows[k])) * W * 16;
-                const size_t src_off = (n_ranks == 1 ? static_cast<size_t>(row) : static_cast<size_t>((row - r) / n_ranks)) * row_bytes;
-                ce = hipMemcpyAsync(reinterpret_cast<char*>(out_rgba) + static_cast<size_t>(row) * row_bytes, src0 + src_off, bytes,
-                                    hipMemcpyDeviceToHost, s->copy_stream);
-                i = j;
-            }
-            if (ce == hipSuccess) ce = hipStreamSynchronize(s->copy_stream);
-            return ce;
+            if (ce != hipSuccess) return ce;
+            return download(s, spans_of(static_cast<const char*>(s->frame.ptr), grp.rows, n_ranks == 1 ? -1 : r), n_ranks == 1);
         };
         if (n_ranks == 1) {
             for (size_t g = 0; g < ranks[0].groups.size() && e == hipSuccess; ++g) {
@@ -1115,31 +1301,44 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* o
             e = first_error;
         }
     } else {
-        // ---- peer gather to the root device, one un-permuting launch, one download
+        // ---- peer gather to the root device; rank by rank: its packed rows arrive (xGMI), one launch un-permutes them
+        // into the frame on the root, its rows travel to the host, its tiles are reported
         mcrt_scene* root = ranks[0].scene;
-        const size_t rank_stride_px = static_cast<size_t>((all.tiles_y + n_ranks - 1) / n_ranks) * T * W;
+        const size_t rank_stride = static_cast<size_t>((all.tiles_y + n_ranks - 1) / n_ranks) * row_bytes;
         char* gathered = static_cast<char*>(root->frame.ptr);  // rank 0 rendered into slot 0 already
-        float* assembled = reinterpret_cast<float*>(gathered + static_cast<size_t>(n_ranks) * rank_stride_px * 16);
-        for (int r = 1; r < n_ranks && e == hipSuccess; ++r) {
+        char* assembled = gathered + static_cast<size_t>(n_ranks) * rank_stride;
+        std::vector<hipEvent_t> unpacked(static_cast<size_t>(n_ranks), nullptr);
+        for (int r = 0; r < n_ranks && e == hipSuccess; ++r) {
             HostRank& hr = ranks[static_cast<size_t>(r)];
-            e = hipSetDevice(hr.device);
             const Shard mine = make_shard(*cfg, r, n_ranks);
-            // behind the rank's render, on the rank's stream: its packed rows to the root's slot r
-            if (e == hipSuccess)
-                e = hipMemcpyPeerAsync(gathered + static_cast<size_t>(r) * rank_stride_px * 16, ranks[0].device, hr.scene->frame.ptr, hr.device,
-                                       static_cast<size_t>(mine.owned_rows) * row_bytes, hr.scene->main_stream);
-            hipEvent_t sent = next_mark(hr.scene);
-            if (e == hipSuccess && !sent) e = hipErrorOutOfMemory;
-            if (e == hipSuccess) e = hipEventRecord(sent, hr.scene->main_stream);
+            if (r > 0) {  // behind the rank's render, on the rank's stream: its packed rows to the root's slot r
+                e = hipSetDevice(hr.device);
+                if (e == hipSuccess)
+                    e = hipMemcpyPeerAsync(gathered + static_cast<size_t>(r) * rank_stride, ranks[0].device, hr.scene->frame.ptr, hr.device,
+                                           static_cast<size_t>(mine.owned_rows) * row_bytes, hr.scene->main_stream);
+                hipEvent_t sent = next_mark(hr.scene);
+                if (e == hipSuccess && !sent) e = hipErrorOutOfMemory;
+                if (e == hipSuccess) e = hipEventRecord(sent, hr.scene->main_stream);
+                if (e == hipSuccess) e = hipSetDevice(ranks[0].device);
+                if (e == hipSuccess) e = hipStreamWaitEvent(root->main_stream, sent, 0);
+            }
             if (e == hipSuccess) e = hipSetDevice(ranks[0].device);
-            if (e == hipSuccess) e = hipStreamWaitEvent(root->main_stream, sent, 0);
+            if (e == hipSuccess)
+                e = px_bytes == 16 ? launch_unpack_rows(*cfg, mine, reinterpret_cast<const float*>(gathered + static_cast<size_t>(r) * rank_stride),
+                                                        reinterpret_cast<float*>(assembled), root->main_stream)
+                                   : launch_unpack_rows8(*cfg, mine, reinterpret_cast<const uint8_t*>(gathered + static_cast<size_t>(r) * rank_stride),
+                                                         reinterpret_cast<uint8_t*>(assembled), root->main_stream);
+            unpacked[static_cast<size_t>(r)] = next_mark(root);
+            if (e == hipSuccess && !unpacked[static_cast<size_t>(r)]) e = hipErrorOutOfMemory;
+            if (e == hipSuccess) e = hipEventRecord(unpacked[static_cast<size_t>(r)], root->main_stream);
         }
-        if (e == hipSuccess) e = hipSetDevice(ranks[0].device);
-        if (e == hipSuccess) e = launch_assemble_frame(*cfg, n_ranks, reinterpret_cast<const float*>(gathered), rank_stride_px, assembled, root->main_stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(out_rgba, assembled, static_cast<size_t>(W) * cfg->height * 16, hipMemcpyDeviceToHost, root->main_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(root->main_stream);
-        if (e == hipSuccess && progress)
-            for (int d = 1; d <= total_tiles; ++d) progress(d, total_tiles, user);
+        for (int r = 0; r < n_ranks && e == hipSuccess; ++r) {
+            e = hipEventSynchronize(unpacked[static_cast<size_t>(r)]);
+            std::vector<int> rows;
+            for (int row = r; row < all.tiles_y; row += n_ranks) rows.push_back(row);
+            if (e == hipSuccess) e = download(root, spans_of(assembled, rows, -1), true);
+            if (e == hipSuccess) report_rows(rows);
+        }
     }
     if (e != hipSuccess) return cleanup(hip_fail(e, "frame download"));
     const double t3 = now_ms();
@@ -1179,7 +1378,7 @@ int mcrt_render_multi(const mcrt_scene_desc* desc, const mcrt_config* cfg, float
     }
     for (int i = 0; i < n_devices; ++i)
         if (devices[i] < 0 || devices[i] >= visible) return fail(MCRT_ERR_NO_DEVICE, "device index out of range");
-    return render_to_host(desc, cfg, out_rgba, progress, user, devices, n_devices, gather ? 1 : 0);
+    return render_to_host(desc, cfg, out_rgba, 16, progress, user, devices, n_devices, gather ? 1 : 0);
 }
 
 int mcrt_render(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_rgba, mcrt_progress_fn progress,
@@ -1190,62 +1389,87 @@ int mcrt_render(const mcrt_scene_desc* desc, const mcrt_config* cfg, float* out_
     if (!out_rgba) return fail(MCRT_ERR_INVALID, "out_rgba is NULL");
     if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
     if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
-    return render_to_host(desc, cfg, out_rgba, progress, user, &device, 1, 0);
+    return render_to_host(desc, cfg, out_rgba, 16, progress, user, &device, 1, 0);
+}
+
+int mcrt_render_rgba8(const mcrt_scene_desc* desc, const mcrt_config* cfg, uint8_t* out_rgba8, mcrt_progress_fn progress, void* user,
+                      const int* devices, int n_devices, int gather) {
+    if (!desc || !cfg) return fail(MCRT_ERR_INVALID, "NULL argument");
+    if (!valid_frame(cfg)) return MCRT_OK;
+    if (!out_rgba8) return fail(MCRT_ERR_INVALID, "out_rgba8 is NULL");
+    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
+    const int visible = mcrt_device_count();
+    if (visible <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    std::vector<int> all;
+    if (!devices || n_devices <= 0) {  // every visible device
+        for (int d = 0; d < visible; ++d) all.push_back(d);
+        devices = all.data();
+        n_devices = visible;
+    }
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= visible) return fail(MCRT_ERR_NO_DEVICE, "device index out of range");
+    return render_to_host(desc, cfg, out_rgba8, 4, progress, user, devices, n_devices, gather ? 1 : 0);
+}
+
+int mcrt_render_rect(const mcrt_scene_desc* desc, const mcrt_config* cfg, const mcrt_tile* tile, float* frame_rgba, int device) {
+    if (!desc || !cfg || !tile || !frame_rgba) return fail(MCRT_ERR_INVALID, "NULL argument");
+    if (cfg->width <= 0 || cfg->height <= 0) return MCRT_OK;
+    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
+    if (tile->width <= 0 || tile->height <= 0) return MCRT_OK;  // renderTile's loops do not run
+    if (tile->x < 0 || tile->y < 0 || tile->x > cfg->width - tile->width || tile->y > cfg->height - tile->height)
+        return fail(MCRT_ERR_INVALID, "tile rectangle reaches outside the frame");
+    mcrt_scene* s = nullptr;
+    int rc = mcrt_scene_create(desc, device, &s);
+    if (rc != MCRT_OK) return rc;
+    s->forced_lanes = 1;  // one stream, like every host-buffer entry point (see render_to_host)
+    s->one_shot = true;
+    const size_t row_floats = static_cast<size_t>(cfg->width) * 4;
+    std::vector<float> host(row_floats * static_cast<size_t>(tile->height));
+    hipError_t e = s->frame.reserve(host.size() * 4);
+    if (e == hipSuccess) {
+        // the rectangle is the launch's one tile; its pixel rows come back packed (full frame width)
+        mcrt_config one = *cfg;
+        if (one.tile_size <= 0) one.tile_size = 1;  // renderTile itself never reads tileSize
+        rc = enqueue_render(s, &one, 0, 1, MCRT_LAYOUT_PACKED, static_cast<float*>(s->frame.ptr), nullptr, nullptr, /*may_record=*/false, nullptr, tile);
+        if (rc == MCRT_OK) rc = mcrt_scene_check(s);
+        if (rc == MCRT_OK) e = hipMemcpy(host.data(), s->frame.ptr, host.size() * 4, hipMemcpyDeviceToHost);
+    }
+    mcrt_scene_destroy(s);
+    if (e != hipSuccess) return hip_fail(e, "render_rect");
+    if (rc != MCRT_OK) return rc;
+    for (int ly = 0; ly < tile->height; ++ly)
+        std::memcpy(frame_rgba + 4 * (static_cast<size_t>(tile->y + ly) * cfg->width + tile->x),
+                    host.data() + row_floats * static_cast<size_t>(ly) + 4 * static_cast<size_t>(tile->x), static_cast<size_t>(tile->width) * 16);
+    return MCRT_OK;
 }
 
 int mcrt_render_tile(const mcrt_scene_desc* desc, const mcrt_config* cfg, int tile_index, float* frame_rgba, int device) {
     if (!desc || !cfg || !frame_rgba) return fail(MCRT_ERR_INVALID, "NULL argument");
     if (!valid_frame(cfg)) return MCRT_OK;
-    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
     Shard all = make_shard(*cfg, 0, 1);
     if (tile_index < 0 || tile_index >= all.tiles_x * all.tiles_y) return fail(MCRT_ERR_INVALID, "tile index out of range");
     const int row = tile_index / all.tiles_x, col = tile_index % all.tiles_x;
-    mcrt_scene* s = nullptr;
-    int rc = mcrt_scene_create(desc, device, &s);
-    if (rc != MCRT_OK) return rc;
-    // render the tile row that contains the tile (a shard of exactly one row), packed
-    s->forced_lanes = 1;  // one stream, like every host-buffer entry point (see render_to_host)
-    const int th = tile_row_height(*cfg, row);
-    const size_t row_floats = static_cast<size_t>(th) * cfg->width * 4;
-    std::vector<float> host(row_floats);
-    hipError_t e = s->frame.reserve(static_cast<size_t>(cfg->tile_size) * cfg->width * 16);
-    if (e == hipSuccess) {
-        rc = enqueue_render(s, cfg, row, all.tiles_y, MCRT_LAYOUT_PACKED, static_cast<float*>(s->frame.ptr), nullptr, nullptr, /*may_record=*/false);
-        if (rc == MCRT_OK) rc = mcrt_scene_check(s);
-        if (rc == MCRT_OK) e = hipMemcpy(host.data(), s->frame.ptr, row_floats * 4, hipMemcpyDeviceToHost);
-    }
-    mcrt_scene_destroy(s);
-    if (e != hipSuccess) return hip_fail(e, "render_tile");
-    if (rc != MCRT_OK) return rc;
-    const int x0 = col * cfg->tile_size, y0 = row * cfg->tile_size;
-    const int tw = std::min(cfg->tile_size, cfg->width - x0);
-    for (int ly = 0; ly < th; ++ly)
-        std::memcpy(frame_rgba + 4 * (static_cast<size_t>(y0 + ly) * cfg->width + x0),
-                    host.data() + 4 * (static_cast<size_t>(ly) * cfg->width + x0), static_cast<size_t>(tw) * 16);
-    return MCRT_OK;
+    mcrt_tile t;
+    t.x = col * cfg->tile_size, t.y = row * cfg->tile_size;
+    t.width = std::min(cfg->tile_size, cfg->width - t.x), t.height = std::min(cfg->tile_size, cfg->height - t.y);
+    return mcrt_render_rect(desc, cfg, &t, frame_rgba, device);
 }
 
 // ---- PNG hand-off: the encoder and the file writers live in png_writer.cpp -------------------------
 int mcrt_render_png(const mcrt_scene_desc* desc, const mcrt_config* cfg, const char* path, int device) {
     if (!desc || !cfg || !path) return fail(MCRT_ERR_INVALID, "NULL argument");
     if (!valid_frame(cfg)) return fail(MCRT_ERR_INVALID, "empty image");
-    if (validate_config(cfg) != MCRT_OK) return MCRT_ERR_INVALID;
-    mcrt_scene* s = nullptr;
-    int rc = mcrt_scene_create(desc, device, &s);
-    if (rc != MCRT_OK) return rc;
-    s->forced_lanes = 1;  // one stream, like every host-buffer entry point (see render_to_host)
     const size_t npix = static_cast<size_t>(cfg->width) * cfg->height;
     std::vector<uint8_t> host(npix * 4);
-    hipError_t e = s->frame.reserve(npix * 4);
-    if (e == hipSuccess) {
-        rc = enqueue_render(s, cfg, 0, 1, MCRT_LAYOUT_FRAME, nullptr, static_cast<uint8_t*>(s->frame.ptr), nullptr, /*may_record=*/false);
-        if (rc == MCRT_OK) rc = mcrt_scene_check(s);
-        if (rc == MCRT_OK) e = hipMemcpy(host.data(), s->frame.ptr, npix * 4, hipMemcpyDeviceToHost);
-    }
-    mcrt_scene_destroy(s);
-    if (e != hipSuccess) return hip_fail(e, "render_png");
+    // the RGBA8 plane straight from the kernels' epilogue: 4 B per pixel over PCIe (and xGMI) instead of 16
+    const int rc = device == MCRT_DEVICE_ALL ? mcrt_render_rgba8(desc, cfg, host.data(), nullptr, nullptr, nullptr, 0, 0)
+                                             : mcrt_render_rgba8(desc, cfg, host.data(), nullptr, nullptr, &device, 1, 0);
     if (rc != MCRT_OK) return rc;
     return mcrt_write_png_rgba8(path, host.data(), cfg->width, cfg->height);
+}
+
+void mcrt_parallel_copy(void* dst, const void* src, size_t bytes) {
+    if (dst && src && bytes) parallel_copy(dst, src, bytes);
 }
 
 int mcrt_last_timings(mcrt_timings* out) {
@@ -1343,13 +1567,21 @@ int mcrt_probe_div_const(int device, uint32_t d_first, uint32_t d_count, int mod
     if (!mismatches || d_first == 0 || d_count == 0 || d_count > 65535u) return fail(MCRT_ERR_INVALID, "bad argument");
     if (mcrt_device_count() <= 0) return fail(MCRT_ERR_NO_DEVICE, "no HIP device");
     HIP_TRY(hipSetDevice(device));
-    DeviceBuffer counts;
+    DeviceBuffer counts, rds;
     HIP_TRY(counts.reserve(16));
+    HIP_TRY(rds.reserve(static_cast<size_t>(d_count) * 4));
+    {  // the reciprocals as the host forms them for the render kernels (prepare(): 1.0f / float(width))
+        std::vector<float> host(d_count);
+        for (uint32_t i = 0; i < d_count; ++i) host[i] = 1.0f / static_cast<float>(d_first + i);
+        HIP_TRY(hipMemcpy(rds.ptr, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    }
     hipError_t e = hipMemset(counts.ptr, 0, 16);
     for (uint32_t off = 0; e == hipSuccess && off < d_count; off += 32) {  // ~12 G quotients per launch
-        e = launch_probe_div_const(d_first + off, d_count - off < 32u ? d_count - off : 32u, mode, static_cast<unsigned long long*>(counts.ptr), nullptr);
+        e = launch_probe_div_const(d_first + off, d_count - off < 32u ? d_count - off : 32u, mode, static_cast<const float*>(rds.ptr) + off,
+                                   static_cast<unsigned long long*>(counts.ptr), nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
+    rds.release();
     unsigned long long host[2] = {0, 0};
     if (e == hipSuccess) e = hipMemcpy(host, counts.ptr, 16, hipMemcpyDeviceToHost);
     counts.release();

@@ -16,7 +16,7 @@
 //            pass by pass for frames that take several);
 //            config.threadCount is accepted and ignored; config.tileSize is honoured (it seeds the
 //            per-tile RNG streams)
-//   :71-127  renderTile: one tile into an existing Image
+//   :71-127  renderTile: one Tile — any rectangle of the frame — into an existing Image
 // The device is chosen with the environment variable MCRT_DEVICE: an index (default 0) or "all" — every
 // visible device renders its cyclic share of the tile rows and downloads it straight into the Image
 // (mcrt_render_multi; MCRT_GATHER=1 assembles on the first device by peer copies instead).
@@ -82,18 +82,13 @@ Image TileRenderer::render(const Scene& scene, const RayTracer::Config& config,
 }
 
 void TileRenderer::renderTile(const Tile& tile, const Scene& scene, const RayTracer::Config& config, Image& output) {
-    if (config.width <= 0 || config.height <= 0 || config.tileSize <= 0) return;
-    if (tile.x % config.tileSize || tile.y % config.tileSize) {
-        errors_.push_back({-1, "renderTile: tile origin is not on the tile grid"});
-        return;
-    }
-    int cols = (config.width + config.tileSize - 1) / config.tileSize;
-    int index = (tile.y / config.tileSize) * cols + tile.x / config.tileSize;
+    if (config.width <= 0 || config.height <= 0) return;
     mcrt_adapter::SceneDescription desc(scene);
     mcrt_config cfg = mcrt_adapter::to_mcrt_config(config);
     const int device = chosen_device() == MCRT_DEVICE_ALL ? 0 : chosen_device();
-    if (mcrt_render_tile(desc.get(), &cfg, index, reinterpret_cast<float*>(output.pixels.data()), device) != MCRT_OK)
-        errors_.push_back({index, mcrt_last_error()});
+    const mcrt_tile t{tile.x, tile.y, tile.width, tile.height};  // any rectangle of the frame, on or off the tile grid
+    if (mcrt_render_rect(desc.get(), &cfg, &t, reinterpret_cast<float*>(output.pixels.data()), device) != MCRT_OK)
+        errors_.push_back({-1, mcrt_last_error()});
 }
 
 const std::vector<TileRenderer::TileError>& TileRenderer::lastErrors() { return errors_; }

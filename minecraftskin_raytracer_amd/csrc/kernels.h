@@ -110,6 +110,13 @@ struct RenderParams {
     int div_frame;         // 1: width and height lie in rt::div_frame's verified range (rt_core.h)
     int bundle_decisions;  // `lit`: 1 — a hit whose whole bundle of shadow rays is decided (rt::bundle_decide) draws no light
                            //    samples and traces no rays; 0 (MCRT_BUNDLE_DECISIONS=0) — every hit's rays are traced
+    int rect_x, rect_y, rect_w, rect_h;  // rect_w > 0: the launch renders ONE tile, this rectangle (TileRenderer::renderTile for an
+                           //    arbitrary Tile, tile_renderer.cpp:71-127: seed rect_y * width + rect_x, pixels in the rectangle's own
+                           //    row-major order); the shard is then one tile row of one tile
+    int plan_wg;           // `plan_tiles`: 1 — a workgroup per tile (four waves twist and consume the stream); 0 — a wave per tile
+    int fold_chase;        // 1 — `primary` follows every chain to its end itself (no `chase` launch): the lone-frame form
+    int lit_raygen;        // `lit`: 1 — the ray lanes form their light sample themselves (skip to draws 2j, 2j+1 of the hit's stream);
+                           //    0 — a lane per undecided record forms all S positions, handed over through LDS
 };
 
 Shard make_shard(const mcrt_config& cfg, int first, int step);
@@ -139,17 +146,23 @@ struct LaunchMarks {
     hipEvent_t after_plan = nullptr;
     hipEvent_t* batch_done = nullptr;
     int n_batch_done = 0;
+    // side branch of a lone frame (all three or none): the background tiles render on `side`, forked from the launch
+    // stream by `side_fork` ahead of plan_tiles and joined by `side_join` behind resolve
+    hipStream_t side = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
 };
 hipError_t launch_render(const RenderParams& p, hipStream_t stream, const LaunchMarks* marks = nullptr);
 
 hipError_t launch_unpack_rows(const mcrt_config& cfg, const Shard& sh, const float* packed, float* frame,
                               hipStream_t stream);
+hipError_t launch_unpack_rows8(const mcrt_config& cfg, const Shard& sh, const uint8_t* packed, uint8_t* frame, hipStream_t stream);  // RGBA8 plane
 hipError_t launch_assemble_frame(const mcrt_config& cfg, int world, const float* gathered, size_t rank_stride_pixels,
                                  float* frame, hipStream_t stream);
 hipError_t launch_quantize(const float* rgba, uint8_t* out, size_t n_pixels, hipStream_t stream);
 // fills table[i] = mt[397] of std::mt19937(i - kSeedWindowHalf) for i < kSeedWindow
 hipError_t launch_build_seed_table(uint32_t* table, hipStream_t stream);
-hipError_t launch_probe_div_const(uint32_t d_first, uint32_t d_count, int mode, unsigned long long* counts, hipStream_t stream);
+// host_reciprocals: d_count floats in device memory, 1.0f / d as the host rounds it (what the render kernels get)
+hipError_t launch_probe_div_const(uint32_t d_first, uint32_t d_count, int mode, const float* host_reciprocals, unsigned long long* counts, hipStream_t stream);
 
 // probes
 hipError_t launch_probe_intersect(const uint8_t* scene, const float* rays, int n, mcrt_hit* out,

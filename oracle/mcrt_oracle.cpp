@@ -720,6 +720,37 @@ int mcrt_oracle_render(const mcrt_scene_desc* scene, const mcrt_config* cfg, flo
     return 0;
 }
 
+// Tile rows row_first, row_first + row_step, ... of the frame by the same thread pool (tile_renderer.cpp:129-189
+// over a subset of generateTiles' tiles); only those rows of out_rgba (a full frame) are written.  Returns the
+// number of tiles rendered.  Used where a whole frame is too slow on the CPU: a cyclic sample of its tile rows.
+int mcrt_oracle_render_rows(const mcrt_scene_desc* scene, const mcrt_config* cfg, int row_first, int row_step, float* out_rgba) {
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->tile_size <= 0 || row_first < 0 || row_step < 1) return 0;
+    int threads = cfg->thread_count;
+    if (threads <= 0) {
+        threads = static_cast<int>(std::thread::hardware_concurrency());
+        if (threads <= 0) threads = 1;
+    }
+    std::vector<mcrt_tile> tiles;
+    for (const mcrt_tile& t : tile_grid(cfg->width, cfg->height, cfg->tile_size)) {
+        const int row = t.y / cfg->tile_size;
+        if (row >= row_first && (row - row_first) % row_step == 0) tiles.push_back(t);
+    }
+    const int total = static_cast<int>(tiles.size());
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int idx = next.fetch_add(1);
+            if (idx >= total) break;
+            render_tile(*scene, *cfg, tiles[static_cast<size_t>(idx)], out_rgba);
+        }
+    };
+    const int n = threads < total ? threads : total;
+    std::vector<std::thread> pool;
+    for (int i = 0; i < n; ++i) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+    return total;
+}
+
 int mcrt_oracle_intersect(const mcrt_scene_desc* scene, const float* rays, int n, mcrt_hit* out) {
     for (int i = 0; i < n; ++i) {
         Ray r{ld3(rays + 6 * i), ld3(rays + 6 * i + 3)};

@@ -24,6 +24,10 @@ int mcrt_oracle_render(const mcrt_scene_desc* scene, const mcrt_config* cfg, flo
 /* TileRenderer::renderTile (tile_renderer.cpp:71-127) for one tile into a full-frame buffer */
 int mcrt_oracle_render_tile(const mcrt_scene_desc* scene, const mcrt_config* cfg,
                             const mcrt_tile* tile, float* frame_rgba);
+/* tile rows row_first, row_first + row_step, ... of the frame on the same thread pool; only those rows of the
+ * full-frame buffer are written.  Returns the number of tiles rendered. */
+int mcrt_oracle_render_rows(const mcrt_scene_desc* scene, const mcrt_config* cfg, int row_first, int row_step,
+                            float* out_rgba);
 /* TileRenderer::generateTiles */
 int mcrt_oracle_generate_tiles(int w, int h, int tile, mcrt_tile* tiles, int capacity);
 /* intersectScene (intersection.cpp:408-421) */

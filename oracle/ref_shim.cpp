@@ -23,6 +23,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <thread>
+#include <atomic>
 #include <map>
 #include <string>
 #include <unistd.h>
@@ -299,6 +302,46 @@ int mcref_render_tile(const mcrt_scene_desc* scene, const mcrt_config* cfg, cons
     TileRenderer::renderTile(t, b->scene, k, img);
     std::memcpy(frame_rgba, img.pixels.data(), img.pixels.size() * sizeof(Color));
     return 0;
+}
+
+// Tile rows row_first, row_first + row_step, ... of the frame, rendered by the reference's own renderTile over a
+// std::thread pool with an atomic tile queue (the structure of TileRenderer::render, tile_renderer.cpp:129-189;
+// threadCount <= 0 -> hardware_concurrency).  Only the pixel rows of those tile rows are written to out_rgba (a full
+// width x height frame).  What bench.py times for frames too large to render whole on the CPU: a cyclic sample of the
+// frame's tile rows, scaled by rows / sampled rows.  Returns the number of tiles rendered.
+int mcref_render_rows(const mcrt_scene_desc* scene, const mcrt_config* cfg, int row_first, int row_step, float* out_rgba) {
+    auto b = build(scene);
+    RayTracer::Config k = to_config(cfg);
+    if (k.width <= 0 || k.height <= 0 || k.tileSize <= 0 || row_first < 0 || row_step < 1) return 0;
+    std::vector<Tile> all = TileRenderer::generateTiles(k.width, k.height, k.tileSize);
+    std::vector<Tile> tiles;
+    for (const Tile& t : all) {
+        const int row = t.y / k.tileSize;
+        if (row >= row_first && (row - row_first) % row_step == 0) tiles.push_back(t);
+    }
+    Image img(k.width, k.height);
+    int threads = k.threadCount;
+    if (threads <= 0) {
+        threads = static_cast<int>(std::thread::hardware_concurrency());
+        if (threads <= 0) threads = 1;
+    }
+    threads = std::min<int>(threads, static_cast<int>(tiles.size()));
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= static_cast<int>(tiles.size())) break;
+            TileRenderer::renderTile(tiles[static_cast<size_t>(i)], b->scene, k, img);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int i = 0; i < threads; ++i) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+    for (const Tile& t : tiles)
+        if (t.x == 0)
+            std::memcpy(out_rgba + 4 * static_cast<size_t>(t.y) * k.width, img.pixels.data() + static_cast<size_t>(t.y) * k.width,
+                        static_cast<size_t>(t.height) * k.width * sizeof(Color));
+    return static_cast<int>(tiles.size());
 }
 
 int mcref_intersect(const mcrt_scene_desc* scene, const float* rays, int n, mcrt_hit* out) {

@@ -41,6 +41,15 @@ class CpuLib:
         self._f("render")(desc_ptr, C.byref(c), abi.fptr(buf), cb, None)
         return out
 
+    def render_rows(self, desc_ptr, cfg: abi.Config, row_first: int, row_step: int, frame: np.ndarray) -> int:
+        """Tile rows row_first, row_first + row_step, ... into `frame` (H, W, 4) on the library's thread pool; returns
+        the number of tiles rendered."""
+        c = cfg.to_c()
+        f = self._f("render_rows")
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(abi.McrtSceneDesc), C.POINTER(abi.McrtConfig), C.c_int, C.c_int, abi.c_float_p]
+        return int(f(desc_ptr, C.byref(c), row_first, row_step, abi.fptr(frame)))
+
     def render_tile(self, desc_ptr, cfg: abi.Config, tile, frame: np.ndarray) -> None:
         c = cfg.to_c()
         t = abi.McrtTile(*tile)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(mcrt):
     for name in declared:
         assert hasattr(lib, name), f"libmcrt.so does not export {name}"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert lib.mcrt_abi_version() == 2
+    assert lib.mcrt_abi_version() == 3
 
 
 def test_struct_layouts_match_header_sizes():
@@ -265,3 +265,18 @@ def test_render_out_argument_is_validated(mcrt):
             mcrt.TileRenderer.render(sd, cfg, out=bad)
     with pytest.raises(ValueError):
         mcrt.TileRenderer.render(sd, cfg, device="some")
+
+
+def test_device_argument_normalisation():
+    """TileRenderer.render's `device`: any integer type is an index, -1 / "all" is every device, other negatives and
+    unknown strings are refused, a sequence lists one rank per entry."""
+    import numpy as np
+    import pytest
+    from minecraftskin_raytracer_amd.api import _devices
+
+    assert _devices(0) == (0, None) and _devices(np.int64(2)) == (2, None) and _devices(np.uint8(1)) == (1, None)
+    assert _devices(-1) == (None, []) and _devices("all") == (None, [])
+    assert _devices([0, np.int32(1), 0]) == (None, [0, 1, 0]) and _devices(()) == (None, [])
+    for bad in (-2, "gpu0", [0, -1], 1.5):
+        with pytest.raises((ValueError, TypeError)):
+            _devices(bad)

@@ -18,6 +18,17 @@ def cpu_has_fma() -> bool:
 
 
 def test_detmath_matches_glibc_fma_variants(tmp_path):
+    check_against_host_libm(tmp_path)
+
+
+@pytest.mark.gpu
+def test_detmath_matches_the_gpu_box_hosts_glibc(tmp_path):
+    """The same check in the `-m gpu` run: it needs no GPU, but the host whose libm the compiled reference (bench.py's
+    cpu_baseline, oracle/_ref) uses there is the GPU box's, not the dev container's."""
+    check_against_host_libm(tmp_path)
+
+
+def check_against_host_libm(tmp_path):
     if not cpu_has_fma():
         pytest.skip("host CPU lacks FMA/AVX2: glibc picks its SSE2 sinf/cosf/powf bodies, which differ in ~1e-8 of inputs")
     exe = tmp_path / "check_detmath"

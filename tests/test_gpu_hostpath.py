@@ -175,3 +175,107 @@ def test_seed_table_can_be_turned_off(mcrt, gpu, tmp_path):
     subprocess.check_call([sys.executable, str(script), a])
     subprocess.check_call([sys.executable, str(script), b], env=dict(os.environ, MCRT_SEED_TABLE="0"))
     assert np.array_equal(np.load(a).view(np.uint32), np.load(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("tile", [(0, 0, 32, 32), (5, 3, 17, 9), (40, 20, 1, 1), (33, 0, 63, 48), (0, 0, 96, 48), (95, 47, 1, 1), (7, 11, 64, 5)])
+def test_render_tile_accepts_any_rectangle(mcrt, oracle, gpu, tile):
+    """TileRenderer::renderTile (tile_renderer.cpp:71-127) takes ANY Tile{x, y, w, h}: its own mt19937(y * W + x), pixels in
+    the rectangle's row-major order, tileSize not read.  Off-grid origins, odd sizes, one pixel, the whole frame as one
+    tile; every other pixel of the output stays as it was."""
+    sd = scenes.skin_scene("S64", 6)
+    cfg = abi.Config(width=96, height=48, maxBounces=3, samplesPerPixel=4, tileSize=16)
+    got = np.full((cfg.height, cfg.width, 4), -7.0, np.float32)
+    want = got.copy()
+    mcrt.TileRenderer._errors = []
+    mcrt.TileRenderer.renderTile(tile, sd, cfg, got)
+    assert mcrt.TileRenderer.lastErrors() == []
+    oracle.render_tile(sd.ptr, cfg, tile, want)
+    scenes.assert_bit_equal(got, want, f"renderTile {tile}")
+
+
+def test_render_tile_with_lens_draws_and_one_sample(mcrt, oracle, gpu):
+    """One sample per pixel and depth of field: the rectangle's stream holds the lens draws only (2 per pixel)."""
+    sd = scenes.skin_scene("S64", 2)
+    cfg = abi.Config(width=80, height=60, maxBounces=2, samplesPerPixel=1, dofEnabled=True, aperture=0.4, aoEnabled=True, aoSamples=4)
+    for tile in [(3, 5, 50, 31), (0, 0, 80, 60)]:
+        got = np.zeros((cfg.height, cfg.width, 4), np.float32)
+        want = got.copy()
+        mcrt.TileRenderer._errors = []
+        mcrt.TileRenderer.renderTile(tile, sd, cfg, got)
+        assert mcrt.TileRenderer.lastErrors() == []
+        oracle.render_tile(sd.ptr, cfg, tile, want)
+        scenes.assert_bit_equal(got, want, f"renderTile {tile} with DOF + AO")
+
+
+def test_render_tile_rejects_rectangles_outside_the_frame(mcrt, gpu):
+    sd = scenes.skin_scene("S64", 0)
+    cfg = abi.Config(width=64, height=64, maxBounces=1, samplesPerPixel=1)
+    out = np.zeros((64, 64, 4), np.float32)
+    for tile in [(60, 0, 8, 8), (0, 60, 8, 8), (-1, 0, 4, 4), (0, 0, 65, 1)]:
+        mcrt.TileRenderer._errors = []
+        mcrt.TileRenderer.renderTile(tile, sd, cfg, out)
+        assert mcrt.TileRenderer.lastErrors() and "outside the frame" in mcrt.TileRenderer.lastErrors()[0][1]
+    mcrt.TileRenderer._errors = []
+    mcrt.TileRenderer.renderTile((4, 4, 0, 9), sd, cfg, out)  # an empty tile: nothing happens
+    assert mcrt.TileRenderer.lastErrors() == [] and not out.any()
+
+
+@pytest.mark.parametrize("device,gather", [(0, False), ([0, 0, 0], False), ([0, 0, 0], True)])
+def test_rgba8_plane_equals_the_quantised_float_frame(mcrt, gpu, device, gather):
+    """mcrt_render_rgba8: the RGBA8 plane quantised in the kernels' epilogue (4 B per pixel on every link) equals
+    ImageWriter's quantiser applied to the float frame, for one device, per-rank downloads and the peer gather."""
+    sd = scenes.skin_scene("S64", 4)
+    cfg = abi.Config(width=333, height=250, maxBounces=4, samplesPerPixel=4)
+    f = mcrt.TileRenderer.render(sd, cfg)
+    q = mcrt.TileRenderer.renderRGBA8(sd, cfg, device=device, gather=gather)
+    assert mcrt.TileRenderer.lastErrors() == []
+    assert np.array_equal(q, mcrt.quantize_rgba8(f))
+
+
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_gather_progress_follows_the_ranks_as_they_land(mcrt, oracle, gpu, ranks):
+    """gather = 1: as each rank's rows have arrived on the first device, been un-permuted and downloaded, that
+    rank's tiles are reported — never ahead of the pixels in the caller's frame."""
+    sd = scenes.skin_scene("S64", 1)
+    cfg = abi.Config(width=300, height=260, maxBounces=3, samplesPerPixel=4)
+    ref = oracle.render(sd.ptr, cfg)
+    total = len(mcrt.TileRenderer.generateTiles(cfg.width, cfg.height, cfg.tileSize))
+    out = np.full((cfg.height, cfg.width, 4), -1.0, np.float32)
+    calls, snaps = [], []
+
+    def cb(done, tot):
+        calls.append((done, tot))
+        if done in (1, total // 2, total):
+            snaps.append((done, out.copy()))
+
+    img = mcrt.TileRenderer.render(sd, cfg, cb, device=[0] * ranks, gather=True, out=out)
+    assert mcrt.TileRenderer.lastErrors() == []
+    assert calls == [(i, total) for i in range(1, total + 1)]
+    scenes.assert_bit_equal(img, ref, "gathered frame vs oracle")
+    for done, snap in snaps:
+        assert tiles_final(snap, ref, cfg) >= done
+    assert tiles_final(snaps[0][1], ref, cfg) < total  # the first report came before the last rank had landed
+
+
+def test_direct_and_staged_downloads_agree(mcrt, gpu, tmp_path):
+    """MCRT_HOST_COPY=direct (hipMemcpyAsync straight into the caller's pages) and the default pinned ring + copy
+    threads deliver the same frame.  (Read once per process → subprocess.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "render.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {repr(root)}); sys.path.insert(0, {repr(os.path.join(root, 'tests'))})\n"
+        "import minecraftskin_raytracer_amd as M, scenes\n"
+        "sd = scenes.skin_scene('S64', 6)\n"
+        "a = M.TileRenderer.render(sd, M.Config(width=1920, height=1080, maxBounces=2, samplesPerPixel=2))\n"
+        "b = M.TileRenderer.render(sd, M.Config(width=200, height=150, maxBounces=2, samplesPerPixel=2), device=[0, 0])\n"
+        "assert M.TileRenderer.lastErrors() == []\n"
+        "np.save(sys.argv[1], a); np.save(sys.argv[2], b)\n")
+    names = [str(tmp_path / n) for n in ("a0.npy", "b0.npy", "a1.npy", "b1.npy")]
+    subprocess.check_call([sys.executable, str(script), names[0], names[1]])
+    subprocess.check_call([sys.executable, str(script), names[2], names[3]], env=dict(os.environ, MCRT_HOST_COPY="direct"))
+    assert np.array_equal(np.load(names[0]).view(np.uint32), np.load(names[2]).view(np.uint32))
+    assert np.array_equal(np.load(names[1]).view(np.uint32), np.load(names[3]).view(np.uint32))

@@ -50,13 +50,13 @@ def test_frame_division_is_the_ieee_division(mcrt, gpu):
     for d in (1, 2, 3, 256, 1080, 1920, 2160, 3840, 4320, 7680, 16383, 16384):
         assert api.probe_div_const(d, 1) == (0, 0), d
     assert api.probe_div_const(601, 300) == (0, 0)
-    import ctypes as C
-    from minecraftskin_raytracer_amd import _lib
-
-    bad, which = C.c_uint64(), C.c_uint32()
-    assert _lib.load().mcrt_probe_div_const(0, 1920, 1, 2, C.byref(bad), C.byref(which)) == 0 and bad.value > 1000000
+    assert api.probe_div_const(1920, 1, mode=2)[0] > 1000000  # the probe's own check: the uncorrected product does differ
     # rt::sqrt_pos (square roots without the general expansion's rescaling of tiny arguments): 0 and every float from 2^-96 to infinity
-    assert _lib.load().mcrt_probe_div_const(0, 1, 1, 3, C.byref(bad), C.byref(which)) == 0 and bad.value == 0
+    assert api.probe_div_const(1, 1, mode=3) == (0, 0)
+    # the reciprocals come from the host (RenderParams::inv_width / inv_height, and the probe's too): the device's own
+    # 1.0f / d agrees with them for every divisor of the verified range
+    for first in range(1, 16385, 4096):
+        assert api.probe_div_const(first, 4096, mode=4) == (0, 0), first
 
 
 def test_detmath_device_random(mcrt, gpu):

@@ -178,6 +178,46 @@ def test_8k_legacy_skin_band_matches_oracle(mcrt, oracle, gpu):
         scenes.assert_bit_equal(f[:, tx * 32:tx * 32 + 32], scratch[row * 32:row * 32 + 32, tx * 32:tx * 32 + 32], f"8k tile {tile}")
 
 
+def test_8k_whole_frame_idempotent_shards_and_oracle_tiles(mcrt, oracle, gpu):
+    """BASELINE.json configs[4] at FULL size: 7680x4320, 8 bounces, 64 spp, legacy 64x32 skin, the single reference
+    light (the reference's Scene holds one Light).  The whole frame: idempotent, equal to its 8 ranks' packed shards
+    re-assembled by the gather root's launch, and equal to the oracle's renderTile on eight tiles — the four that
+    hold most of the figure, the frame's corners and two background tiles (tile_renderer.cpp:71-127)."""
+    sd = scenes.skin_scene("S32", 0)
+    ds = mcrt.DeviceScene(sd)
+    cfg = abi.Config(width=7680, height=4320, maxBounces=8, samplesPerPixel=64)
+    frame = render_dev(mcrt, ds, cfg)
+    again = render_dev(mcrt, ds, cfg)
+    assert torch.equal(frame, again)
+    del again
+    from minecraftskin_raytracer_amd import parallel
+
+    world = 8
+    rows = parallel.packed_rows(cfg, world)
+    st = torch.cuda.current_stream().cuda_stream
+    gathered = torch.full((world, rows, cfg.width, 4), -3.0, dtype=torch.float32, device="cuda")
+    for r in range(world):
+        ds.render_device(cfg, gathered[r].data_ptr(), r, world, abi.LAYOUT_PACKED, st)
+    rebuilt = torch.zeros_like(frame)
+    mcrt.assemble_frame_device(cfg, world, gathered.data_ptr(), rows * cfg.width, rebuilt.data_ptr(), st)
+    torch.cuda.synchronize()
+    ds.check()
+    assert torch.equal(rebuilt, frame)
+    del rebuilt, gathered
+    f = frame.cpu().numpy()
+    ds.close()
+    assert np.isfinite(f).all() and f.min() >= 0.0 and f.max() <= 1.0 and (f[..., 3] == 1.0).all()
+    tiles = oracle.generate_tiles(cfg.width, cfg.height, cfg.tileSize)
+    assert len(tiles) == 240 * 135
+    bgdiff = np.abs(f[..., :3] - f[0, 0, :3]).sum(axis=2) > 0.2
+    weight = [bgdiff[y:y + h, x:x + w].sum() for x, y, w, h in tiles]
+    scratch = np.zeros_like(f)
+    for i in list(np.argsort(weight)[-4:]) + [0, len(tiles) - 1, 239, 240 * 67 + 5]:
+        oracle.render_tile(sd.ptr, cfg, tiles[i], scratch)
+        x, y, w, h = tiles[i]
+        scenes.assert_bit_equal(f[y:y + h, x:x + w], scratch[y:y + h, x:x + w], f"8k tile {i} {tiles[i]}")
+
+
 def test_culling_never_changes_the_image(mcrt, gpu):
     # dofEnabled with aperture below the 1e-6 gate renders the pinhole path; enabling DOF with a tiny
     # aperture above the gate disables primary-ray culling.  A direct A/B of the culled kernel: render

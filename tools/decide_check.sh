@@ -1,14 +1,14 @@
 #!/bin/bash
-# Verification build of `lit`'s whole-bundle shadow decisions (rt_core.h: bundle_decide): compiled with
-# -DMCRT_DECIDE_CHECK every record's rays are traced even when the bundle was decided, and a decision the traced rays
-# contradict is printed and counted.  usage: tools/decide_check.sh build   (here, no GPU needed)
+# Verification build of `lit`'s whole-bundle shadow decisions (rt_core.h: bundle_decide): compiled with the hooks of
+# tools/decide_check_hooks.h (-DMCRT_KERNEL_HOOKS) every record's rays are traced even when the bundle was decided, and a
+# decision the traced rays contradict is printed and counted.  The product library contains none of this.  usage: tools/decide_check.sh build   (here, no GPU needed)
 #                                            tools/decide_check.sh run [first_seed count]   (on the GPU box)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 C=$R/minecraftskin_raytracer_amd/csrc
 if [ "$1" = build ]; then
   mkdir -p $R/variants
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I$R/include -I$C -DMCRT_DECIDE_CHECK \
-    $C/render_kernels.hip $C/api.cpp $C/flatten.cpp $C/scene_builder.cpp $C/png_writer.cpp -o $R/variants/decide_check.so -lpthread
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I$R/include -I$C -I$R/tools '-DMCRT_KERNEL_HOOKS="decide_check_hooks.h"' \
+    $C/render_kernels.hip $C/api.cpp $C/flatten.cpp $C/scene_builder.cpp $C/png_writer.cpp $C/copy_pool.cpp -o $R/variants/decide_check.so -lpthread
   exit $?
 fi
 first=${2:-900000}; count=${3:-2000}
