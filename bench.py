@@ -386,6 +386,13 @@ def main() -> None:
         walls, splits = timed(n_calls)  # out=None: a new Image(W, H) = (0,0,0,1) per call, inside the timed region
         host = np.zeros((h, w, 4), np.float32)
         reused, _ = timed(n_calls, out=host)
+        untouched = []
+        for _ in range(5):  # a destination whose pages were never touched (np.empty): the library takes its pinned ring
+            fresh = np.empty((h, w, 4), np.float32)
+            t0 = time.perf_counter()
+            M.TileRenderer.render(sd, cfg, out=fresh)
+            untouched.append((time.perf_counter() - t0) * 1e3)
+            del fresh
         med = statistics.median(walls)
         render_call = {
             "ms": round(med, 4),
@@ -394,9 +401,11 @@ def main() -> None:
             "min_ms": round(min(walls), 4),
             "split_ms": {k: round(statistics.median(t[k] for t in splits), 4) for k in splits[0]},
             "reused_buffer_ms": round(statistics.median(reused), 4),
+            "untouched_buffer_ms": round(statistics.median(untouched), 4),
             "what": "median wall time of TileRenderer.render (mcrt_render behind it) returning a FRESH Image per call, as the reference's call "
-                    "site gets one: Image(W,H) allocation and (0,0,0,1) fill + scene flatten + upload + kernels + rows through the pinned ring "
-                    "into the new pages + progress bookkeeping; reused_buffer_ms = the same call into one caller-owned buffer; split_ms = the "
+                    "site gets one: Image(W,H) allocation and (0,0,0,1) fill + scene flatten + upload + kernels + row-group downloads "
+                    "overlapping the render + progress bookkeeping; reused_buffer_ms = the same call into one caller-owned buffer; "
+                    "untouched_buffer_ms = into never-touched pages (np.empty: rows go through the pinned ring and copy threads); split_ms = the "
                     "library's own split of the C call (mcrt_last_timings)",
         }
         if not args.quick_host:

@@ -73,7 +73,13 @@ struct FlatHeader {  // 192 bytes
     float cam_fwd[3];
     float cam_focus_auto;  // |target - position|      (tile_renderer.cpp:82-85)
     float cam_right[3];
-    float pad0;
+    // Slack of the conservative candidate masks (rt_core.h: bundle_classify, ball / hemisphere candidates) and of the
+    // bounds that only ever SKIP work (bounding spheres, screen bounds), in world units: kMaskSlack x the largest
+    // coordinate magnitude of the scene (box corners, pivots, light, camera) — ~330 ulp of that magnitude, the float
+    // error of the per-ray arithmetic being a few ulp of it.  Scale-free: a scene scaled or moved far from the origin
+    // keeps the same margin in ulps.  2e-3 for the reference's character scene (camera 50 away); +inf for a scene
+    // with non-finite coordinates (every mesh is then a candidate of every query).
+    float mask_slack;
     float cam_up[3];  // trueUp = right x forward
     float pad1;
     float background[4];
@@ -86,6 +92,8 @@ struct FlatHeader {  // 192 bytes
     uint32_t root_lo, root_hi;  // bit i: mesh i (< 64) is a group root (every mesh is in exactly one group)
     uint32_t pad2[9];
 };
+
+constexpr float kMaskSlack = 4e-5f;
 
 static_assert(sizeof(FlatMesh) == 192, "FlatMesh layout");
 static_assert(sizeof(FlatHeader) == 192, "FlatHeader layout");

@@ -13,6 +13,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <limits>
 #include <cstring>
 
 namespace mcrt {
@@ -146,13 +147,33 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
     h->alpha_offset = static_cast<uint32_t>(alpha_off);
     h->alpha_words = static_cast<uint32_t>(alpha_words);
 
+    // ---- magnitude of the scene's coordinates → slack of everything that is merely conservative (flat_scene.h) ----
+    double mag = 0.0;
+    {
+        auto take = [&](double v) { mag = (std::isfinite(v) ? std::fmax(mag, std::fabs(v)) : std::numeric_limits<double>::infinity()); };
+        for (int k = 0; k < 3; ++k) take(d->camera_position[k]), take(d->light_position[k]);
+        take(d->light_radius);
+        for (int i = 0; i < d->n_meshes && std::isfinite(mag); ++i) {
+            const mcrt_mesh& m = d->meshes[i];
+            if (m.n_triangles > 0 && m.tri_vertices)
+                for (int v = 0; v < m.n_triangles * 9; ++v) take(m.tri_vertices[v]);
+            if (m.n_local_triangles > 0 && m.local_tri_vertices)
+                for (int v = 0; v < m.n_local_triangles * 9; ++v) take(m.local_tri_vertices[v]);
+            if (m.has_rotation)
+                for (int k = 0; k < 3; ++k) take(m.pivot[k]);
+        }
+    }
+    const double slack_d = static_cast<double>(kMaskSlack) * mag;
+    h->mask_slack = std::isfinite(slack_d) ? static_cast<float>(slack_d) : std::numeric_limits<float>::infinity();
+    const double slack = std::isfinite(slack_d) ? slack_d : 0.0;  // (non-finite scenes get no bounds at all below)
+
     // Culling is only offered for a well-conditioned pinhole camera: orthonormal basis, finite
     // positive tan(fov/2).  Anything else renders every mesh for every primary ray.
     auto finite3 = [](V3 v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
     bool cull_ok = finite3(pos) && finite3(fwd) && finite3(right) && finite3(up) &&
                    std::fabs(length(fwd) - 1.0f) < 1e-3f && std::fabs(length(right) - 1.0f) < 1e-3f &&
                    std::fabs(length(up) - 1.0f) < 1e-3f && std::isfinite(half_h) && half_h > 1e-4f &&
-                   half_h < 1e4f;
+                   half_h < 1e4f && std::isfinite(slack_d);
     h->cull_ok = cull_ok ? 1u : 0u;
 
     // ---- meshes -----------------------------------------------------------------------------
@@ -231,7 +252,8 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
             f.sphere[0] = static_cast<float>(w[0]);
             f.sphere[1] = static_cast<float>(w[1]);
             f.sphere[2] = static_cast<float>(w[2]);
-            f.sphere[3] = (ntri > 0 && std::isfinite(r)) ? static_cast<float>(r * 1.01 + 0.05) : -1.0f;  // < 0: no bound
+            // padded by 1 % and 25 slacks (0.05 at the reference's scale): the posed corners are formed in float by the kernels
+            f.sphere[3] = (ntri > 0 && std::isfinite(r) && std::isfinite(slack_d)) ? static_cast<float>(r * 1.01 + 25.0 * slack) : -1.0f;  // < 0: no bound
         }
 
         // Conservative screen bound: project the 8 box corners (posed ones rotated forward) and
@@ -241,7 +263,8 @@ bool flatten_scene(const mcrt_scene_desc* d, std::vector<uint8_t>& blob, std::st
         bool bound_ok = cull_ok && ntri > 0;
         double u0 = 1e30, v0 = 1e30, u1 = -1e30, v1 = -1e30, z0 = 1e30, z1 = -1e30;
         for (int c = 0; c < 8 && bound_ok; ++c) {
-            double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+            // the box inflated by one slack: a ray the float slab test lets graze the box still projects inside the bound
+            double p[3] = {(c & 1) ? hi[0] + slack : lo[0] - slack, (c & 2) ? hi[1] + slack : lo[1] - slack, (c & 4) ? hi[2] + slack : lo[2] - slack};
             double w[3];
             if (rotated)
                 rotate_fwd_d(m, p, w);

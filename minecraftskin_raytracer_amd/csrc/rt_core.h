@@ -787,8 +787,11 @@ DEV bool any_hit_masked(const SV& sc, const Ray& r, float limit, unsigned long l
 template <bool kPosed, class SV>
 DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
     const V3 D = L - O;
-    const float Rb = R * 1.001f + 1e-6f;
-    const float slack = 2e-3f;
+    // every margin of the test is a multiple of the scene's slack (flat_scene.h: kMaskSlack x the scene's coordinate
+    // magnitude, 2e-3 at the reference's scale), so the test keeps its margin in ulps however the scene is scaled or placed
+    const float slack = sc.hdr->mask_slack;
+    const float Rb = R * 1.001f + 1e-3f * slack;
+    const float flat = 1e-3f * slack + 1e-37f, tol = 5e-3f * slack;
     unsigned long long cand = 0ull;
     const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
     const unsigned long long roots = sc.roots;
@@ -798,7 +801,7 @@ DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
         const MeshData m = mesh_uniform(sc, i);
         if (m.flags & MESH_EMPTY) continue;
         // posed mesh: the same test in the mesh's local frame — the rotation is rigid, so the bundle keeps
-        // its radius; the float error of rotating two points (~1e-5 at scene scale) is far inside the slack
+        // its radius; the float error of rotating two points (a few ulp of the coordinates) is far inside the slack
         V3 o = O, d = D;
         if (kPosed && (m.flags & MESH_ROTATED)) {
             const bool ax = (m.flags & MESH_APPLY_X) != 0, az = (m.flags & MESH_APPLY_Z) != 0;
@@ -820,9 +823,9 @@ DEV unsigned long long bundle_candidates(const SV& sc, V3 O, V3 L, float R) {
                 const float al = d1 + Rb, bl = l - slack - o1;  // al·s >= bl
                 const float ah = d1 - Rb, bh = h + slack - o1;  // ah·s <= bh
                 const float ql = bl * __builtin_amdgcn_rcpf(al), qh = bh * __builtin_amdgcn_rcpf(ah);
-                const bool flat_l = __builtin_fabsf(al) < 1e-6f, flat_h = __builtin_fabsf(ah) < 1e-6f;
+                const bool flat_l = __builtin_fabsf(al) < flat, flat_h = __builtin_fabsf(ah) < flat;
                 // flat: the inequality does not depend on s (holds iff 0 >= bl resp. 0 <= bh; tiny margin)
-                ok = ok & !(flat_l & (bl > 1e-5f)) & !(flat_h & (bh < -1e-5f));
+                ok = ok & !(flat_l & (bl > tol)) & !(flat_h & (bh < -tol));
                 s_in = (!flat_l & (al > 0.0f)) ? smax(s_in, ql - 1e-5f) : s_in;
                 s_out = (!flat_l & (al < 0.0f)) ? smin(s_out, ql + 1e-5f) : s_out;
                 s_out = (!flat_h & (ah > 0.0f)) ? smin(s_out, qh + 1e-5f) : s_out;
@@ -913,7 +916,9 @@ DEV int bundle_decide_mesh(const SV& sc, const MeshData& m, int mesh_index, cons
     if ((ax & (g.nlo.x > 0.0f)) | (bx & (g.nhi.x < 0.0f)) | (ay & (g.nlo.y > 0.0f)) | (by & (g.nhi.y < 0.0f)) | (az & (g.nlo.z > 0.0f)) |
         (bz & (g.nhi.z < 0.0f)))
         return BUNDLE_MISS;
-    const float scale = smax(smax(1.0f, g.omax), smax(max3abs(lo), max3abs(hi)));
+    // the numbers involved: the origin, the box, and never less than a fiftieth of the scene's coordinate magnitude (500
+    // slacks: 1.0 at the reference's scale) — a floor that moves with the scene instead of an absolute one
+    const float scale = smax(smax(500.0f * sc.hdr->mask_slack, g.omax), smax(max3abs(lo), max3abs(hi)));
     const float mg = 2e-5f * scale;  // >= 8 x the float error of a crossing point (a few ulp of box-sized numbers)
     const int n_out = static_cast<int>(ax | bx) + static_cast<int>(ay | by) + static_cast<int>(az | bz);
     if (n_out > 1) return BUNDLE_UNKNOWN;
@@ -1046,11 +1051,11 @@ struct SegAxis {
     float c_in_lo, k_in_lo, c_out_lo, k_out_lo;  // from the min face
     float c_in_hi, k_in_hi, c_out_hi, k_out_hi;  // from the max face
 };
-DEV SegAxis seg_axis(float d1, float Rb) {
+DEV SegAxis seg_axis(float d1, float Rb, float nudge) {
     float al = d1 + Rb, ah = d1 - Rb;
-    // a vanishing coefficient (a constraint that does not depend on s) is nudged to 1e-6: far inside the test's slack
-    al = __builtin_fabsf(al) < 1e-6f ? 1e-6f : al;
-    ah = __builtin_fabsf(ah) < 1e-6f ? 1e-6f : ah;
+    // a vanishing coefficient (a constraint that does not depend on s) is nudged to a thousandth of the test's slack
+    al = __builtin_fabsf(al) < nudge ? nudge : al;
+    ah = __builtin_fabsf(ah) < nudge ? nudge : ah;
     const float ial = __builtin_amdgcn_rcpf(al), iah = __builtin_amdgcn_rcpf(ah);
     const float big = 1e30f, eps = 1e-5f;
     SegAxis c;
@@ -1060,8 +1065,7 @@ DEV SegAxis seg_axis(float d1, float Rb) {
     c.c_in_hi = ah > 0.0f ? 0.0f : iah, c.k_in_hi = ah > 0.0f ? -big : -eps;  //              ah < 0: s >= bh / ah
     return c;
 }
-DEV void seg_axis_apply(const SegAxis& c, float o1, float l, float h, float& s_in, float& s_out) {
-    const float slack = 2e-3f;
+DEV void seg_axis_apply(const SegAxis& c, float o1, float l, float h, float slack, float& s_in, float& s_out) {
     const float bl = (l - o1) - slack, bh = (h - o1) + slack;
     s_in = __builtin_fmaxf(s_in, __builtin_fmaxf(__builtin_fmaf(bl, c.c_in_lo, c.k_in_lo), __builtin_fmaf(bh, c.c_in_hi, c.k_in_hi)));
     s_out = __builtin_fminf(s_out, __builtin_fminf(__builtin_fmaf(bl, c.c_out_lo, c.k_out_lo), __builtin_fmaf(bh, c.c_out_hi, c.k_out_hi)));
@@ -1072,8 +1076,9 @@ DEV int bundle_classify(const SceneView& scg, const SV& sc, V3 O, V3 L, float R,
     const BundleGeom g = bundle_geom(O, L, R, 0.0f);
     decide = decide && g.ok && scg.n_meshes <= 64;  // meshes beyond the mask are tested per ray
     const V3 D = L - O;
-    const float Rb = R * 1.001f + 1e-6f;
-    const SegAxis cx = seg_axis(D.x, Rb), cy = seg_axis(D.y, Rb), cz = seg_axis(D.z, Rb);
+    const float slack = scg.hdr->mask_slack;  // kMaskSlack x the scene's coordinate magnitude (flat_scene.h): scale-free margins
+    const float Rb = R * 1.001f + 1e-3f * slack, nudge = 1e-3f * slack + 1e-37f;
+    const SegAxis cx = seg_axis(D.x, Rb, nudge), cy = seg_axis(D.y, Rb, nudge), cz = seg_axis(D.z, Rb, nudge);
     // moving away from a box (exact, see bundle_decide_mesh), as floats: up = -1 where every target lies above the
     // origin on that axis, dn = 1 where below; the rule holds iff up·(hi - O) > 0 or dn·(lo - O) > 0 (float
     // subtraction keeps the sign of the comparison)
@@ -1099,16 +1104,16 @@ DEV int bundle_classify(const SceneView& scg, const SV& sc, V3 O, V3 L, float R,
             };
             const V3 o = to_mesh(O);
             const V3 d = to_mesh(L) - o;
-            seg_axis_apply(seg_axis(d.x, Rb), o.x, m.lo.x, m.hi.x, s_in, s_out);
-            seg_axis_apply(seg_axis(d.y, Rb), o.y, m.lo.y, m.hi.y, s_in, s_out);
-            seg_axis_apply(seg_axis(d.z, Rb), o.z, m.lo.z, m.hi.z, s_in, s_out);
+            seg_axis_apply(seg_axis(d.x, Rb, nudge), o.x, m.lo.x, m.hi.x, slack, s_in, s_out);
+            seg_axis_apply(seg_axis(d.y, Rb, nudge), o.y, m.lo.y, m.hi.y, slack, s_in, s_out);
+            seg_axis_apply(seg_axis(d.z, Rb, nudge), o.z, m.lo.z, m.hi.z, slack, s_in, s_out);
         } else {  // its members lie inside the root's box: moving away from it is moving away from them
             away = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(upx * (m.hi.x - O.x), dnx * (m.lo.x - O.x)),
                                                    __builtin_fmaxf(upy * (m.hi.y - O.y), dny * (m.lo.y - O.y))),
                                    __builtin_fmaxf(upz * (m.hi.z - O.z), dnz * (m.lo.z - O.z)));
-            seg_axis_apply(cx, O.x, m.lo.x, m.hi.x, s_in, s_out);
-            seg_axis_apply(cy, O.y, m.lo.y, m.hi.y, s_in, s_out);
-            seg_axis_apply(cz, O.z, m.lo.z, m.hi.z, s_in, s_out);
+            seg_axis_apply(cx, O.x, m.lo.x, m.hi.x, slack, s_in, s_out);
+            seg_axis_apply(cy, O.y, m.lo.y, m.hi.y, slack, s_in, s_out);
+            seg_axis_apply(cz, O.z, m.lo.z, m.hi.z, slack, s_in, s_out);
         }
         const bool pass = !(away > 0.0f) & !(s_in > s_out);
         if (pass) keep |= m.group;
@@ -1140,7 +1145,7 @@ DEV int bundle_classify(const SceneView& scg, const SV& sc, V3 O, V3 L, float R,
 // sphere when posed) comes within `radius` of O can matter.
 template <bool kPosed, class SV>
 DEV unsigned long long ball_candidates(const SV& sc, V3 O, float radius) {
-    const float reach = radius * 1.001f + 2e-3f;
+    const float reach = radius * 1.001f + sc.hdr->mask_slack;  // scale-free: flat_scene.h
     unsigned long long cand = 0ull;
     const int n = sc.n_meshes < 64 ? sc.n_meshes : 64;
     const unsigned long long roots = sc.roots;
@@ -1175,7 +1180,7 @@ DEV unsigned long long ball_candidates(const SV& sc, V3 O, float radius) {
 // (intersection.cpp:222-249), whatever its direction.  Exact; posed meshes and other normals are left alone.
 template <bool kPosed, class SV>
 DEV unsigned long long hemisphere_candidates(const SV& sc, V3 O, V3 N, float radius) {
-    const float reach = radius * 1.001f + 2e-3f;
+    const float reach = radius * 1.001f + sc.hdr->mask_slack;  // scale-free: flat_scene.h
     // the normal as an axis: n_c = ±1 on one axis and ±0 on the others, else no pruning (all limits stay open)
     const bool axial = (__builtin_fabsf(N.x) == 1.0f & N.y == 0.0f & N.z == 0.0f) | (N.x == 0.0f & __builtin_fabsf(N.y) == 1.0f & N.z == 0.0f) |
                        (N.x == 0.0f & N.y == 0.0f & __builtin_fabsf(N.z) == 1.0f);

@@ -107,7 +107,10 @@ def _box_scene(g):
     return meshes, centre
 
 
-def make_bundle_case(seed: int):
+def make_bundle_case(seed: int, wide: bool = False):
+    """wide: the scene is also scaled by 1e-5 ... 1e6 or moved 1e3 ... 1e6 away from the origin (coordinates whose ulp is
+    as large as 0.06), with lights much smaller than the scene — the margins of the conservative masks and of the
+    decisions are multiples of the scene's coordinate magnitude (flat_scene.h: mask_slack), not absolute numbers."""
     import scenes
 
     g = np.random.default_rng(seed ^ 0x5EED0000)
@@ -151,20 +154,35 @@ def make_bundle_case(seed: int):
     sc.camera_up = (0.0, 1.0, 0.0)
     # the whole scene scaled (margins of the decisions are relative to the scene's size)
     scale = float([1.0, 1.0, 1.0, 1e-3, 0.05, 30.0, 1e4][g.integers(0, 7)])
-    if scale != 1.0:
+    shift = np.zeros(3, np.float32)
+    if wide:  # (an own generator: the draws above keep their meaning)
+        gw = np.random.default_rng(seed ^ 0x77EED000)
+        r = gw.random()
+        if r < 0.45:
+            scale = float([1e-5, 1e-4, 1e5, 1e6, 3e5][gw.integers(0, 5)])
+        elif r < 0.9:
+            scale = 1.0
+            shift = (gw.choice([1e3, 1e4, 1e5, 1e6, 3e6]) * gw.choice([-1.0, 1.0], 3) * (gw.random(3) < 0.6)).astype(np.float32)
+        if gw.random() < 0.4:
+            sc.light_radius = float([1e-4, 1e-3, 0.02][gw.integers(0, 3)])  # a light much smaller than the scene
+    if scale != 1.0 or shift.any():
         s32 = np.float32(scale)
         for m in sc.meshes:
-            m.triangles = (np.asarray(m.triangles, np.float32) * s32).astype(np.float32)
+            m.triangles = (np.asarray(m.triangles, np.float32) * s32 + np.tile(shift, 3)).astype(np.float32)
             if m.localTriangles is not None:
-                m.localTriangles = (np.asarray(m.localTriangles, np.float32) * s32).astype(np.float32)
-            m.pivot = tuple(float(np.float32(x) * s32) for x in m.pivot)
-        sc.light_position = tuple(float(np.float32(x) * s32) for x in sc.light_position)
+                m.localTriangles = (np.asarray(m.localTriangles, np.float32) * s32 + np.tile(shift, 3)).astype(np.float32)
+            m.pivot = tuple(float(np.float32(x) * s32 + t) for x, t in zip(m.pivot, shift))
+        sc.light_position = tuple(float(np.float32(x) * s32 + t) for x, t in zip(sc.light_position, shift))
         sc.light_radius = float(np.float32(sc.light_radius) * s32)
-        sc.camera_position = tuple(float(np.float32(x) * s32) for x in sc.camera_position)
-        sc.camera_target = tuple(float(np.float32(x) * s32) for x in sc.camera_target)
+        sc.camera_position = tuple(float(np.float32(x) * s32 + t) for x, t in zip(sc.camera_position, shift))
+        sc.camera_target = tuple(float(np.float32(x) * s32 + t) for x, t in zip(sc.camera_target, shift))
     w, h = int(g.integers(24, 120)), int(g.integers(24, 90))
     kw = dict(width=w, height=h, maxBounces=int([0, 1, 2, 4][g.integers(0, 4)]), samplesPerPixel=int([1, 2, 4][g.integers(0, 3)]),
               tileSize=int([8, 16, 32, 32][g.integers(0, 4)]), shadowSamples=int([2, 3, 4, 8, 8, 8, 16, 32][g.integers(0, 8)]))
     if g.random() < 0.1:
         kw.update(aoEnabled=True, aoSamples=int([2, 8][g.integers(0, 2)]), aoRadius=float(g.uniform(0.5, 4) * scale))
-    return M.SceneDesc(sc), abi.Config(**kw), f"bundle seed {seed}: {what} light {np.round(lp, 3).tolist()} r {sc.light_radius} scale {scale} {kw}"
+    return M.SceneDesc(sc), abi.Config(**kw), f"bundle seed {seed}: {what} light {np.round(lp, 3).tolist()} r {sc.light_radius} scale {scale} shift {shift.tolist()} {kw}"
+
+
+def make_wide_case(seed: int):
+    return make_bundle_case(seed, wide=True)

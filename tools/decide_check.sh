@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
 fi
 first=${2:-900000}; count=${3:-2000}
 export MCRT_LIB=$R/variants/decide_check.so MCRT_GRAPH=0
-for mode in "" bundle; do
+for mode in "" bundle wide; do
   timeout -k 10 900 python3 $R/tools/gpu_fuzz.py $first $count $mode 2>&1 | grep -a "DECIDE_CHECK\|fuzz:" | python3 -c "
 import sys, re
 tot = [0, 0, 0, 0]; bad = []
