@@ -109,9 +109,6 @@ struct RngKey {
 struct Lane {
     hipStream_t stream = nullptr;  // owned; unused for lane 0
     hipEvent_t done = nullptr;
-    // side branch of a lone frame: the background tiles render beside the chain of the tiles that hold the figure
-    hipStream_t side = nullptr;
-    hipEvent_t side_fork = nullptr, side_join = nullptr;
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
     DeviceBuffer tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queues[5], texel_refs, targets, cand, lit[2], stack, counters, hit_rng;
     RngKey rng_key;               // which tile seeds tile_rng holds (ptr == nullptr: none)
@@ -126,7 +123,6 @@ struct mcrt_scene {
     DeviceBuffer blob;
     Lane lanes[kMaxLanes];
     int forced_lanes = 0;  // mcrt_scene_set_lanes: 0 = automatic
-    bool one_shot = false;  // a host-buffer render (mcrt_render & co): one frame at a time on one stream
     size_t budget = 0;     // current workspace budget (0 = workspace_budget()); halved when the device is short of memory
     // recorded launch sequences of recent renders (hipGraph), replayed when the parameters repeat
     struct Recorded {
@@ -165,6 +161,8 @@ struct mcrt_scene {
     hipEvent_t ring_ev[16] = {};
     const uint32_t* seed_table = nullptr;  // the device's table of mt19937 seeding results (kernels.h), or NULL
     bool holds_seed_table = false;
+    const uint32_t* seed_table_full = nullptr;  // the device's table for every 32-bit seed (ambient occlusion), or NULL
+    bool holds_full_table = false, full_table_tried = false;
 };
 
 namespace {
@@ -261,15 +259,7 @@ void touched_tiles_per_row(const mcrt_scene* sc, const mcrt_config& cfg, const S
     }
 }
 
-// development knobs: -1 = the library's choice, 0 / 1 forced
-int env_tristate(const char* name) {
-    const char* e = std::getenv(name);
-    if (!e || !e[0]) return -1;
-    return std::atoi(e) != 0 ? 1 : 0;
-}
-// A handle whose caller has not said that it keeps several frames in flight itself (mcrt_scene_set_lanes(n >= 1)) renders
-// ONE frame at a time: what counts is the length of the frame's dependent chain, not the instruction count.
-bool lone_frame(const mcrt_scene* s) { return s->forced_lanes == 0 || s->one_shot; }
+const uint32_t* acquire_full_seed_table(int device);  // below, with the per-device tables
 
 // fill RenderParams for lane `li` of `n_lanes` over the shard (first, step) + make sure its
 // workspace exists (allocation only when it has to grow)
@@ -279,19 +269,13 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     std::memset(&p, 0, sizeof p);
     p.scene = static_cast<const uint8_t*>(sc->blob.ptr);
     p.seed_table = sc->seed_table;
+    p.seed_table_full = sc->seed_table_full;
     {
         static const bool decisions = [] {  // development knob: MCRT_BUNDLE_DECISIONS=0 traces every hit's shadow rays
             const char* e = std::getenv("MCRT_BUNDLE_DECISIONS");
             return !(e && e[0] == '0');
         }();
         p.bundle_decisions = decisions ? 1 : 0;
-    }
-    {
-        static const int plan_wg = env_tristate("MCRT_PLAN_WG"), fold = env_tristate("MCRT_FOLD_CHASE"), raygen = env_tristate("MCRT_LIT_RAYGEN");
-        // measured on the MI355X (profiles/r03_*): none of the three pays at the metric frame — the defaults are off
-        p.plan_wg = plan_wg < 0 ? 0 : plan_wg;
-        p.fold_chase = fold < 0 ? 0 : fold;
-        p.lit_raygen = raygen < 0 ? 0 : raygen;
     }
     p.cfg = *cfg;
     if (cfg->width > 0 && cfg->height > 0) {
@@ -444,8 +428,8 @@ constexpr int kMaxBounces = 4000;
 // that depends on data lives on the device), so it is recorded once through stream capture on a private
 // stream, lanes included, and replayed with a single hipGraphLaunch: ~75 us of launch calls per render
 // become one.
-int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream, bool may_record, const LaunchMarks* marks) {
-    if (!graphs_enabled() || !may_record) return launch_lanes(s, p, n_lanes, stream, marks);
+int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t stream, bool may_record) {
+    if (!graphs_enabled() || !may_record) return launch_lanes(s, p, n_lanes, stream);
     ++s->use_clock;
     mcrt_scene::Recorded* slot = nullptr;
     for (auto& r : s->recorded)
@@ -476,11 +460,11 @@ int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStrea
             slot = victim;
         }
         slot->last_use = s->use_clock;
-        if (++slot->sightings < kRecordAt) return launch_lanes(s, p, n_lanes, stream, marks);
+        if (++slot->sightings < kRecordAt) return launch_lanes(s, p, n_lanes, stream);
         if (!s->capture_stream) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
         hipError_t e = hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            const int rc = launch_lanes(s, p, n_lanes, s->capture_stream, marks);
+            const int rc = launch_lanes(s, p, n_lanes, s->capture_stream);
             hipGraph_t g = nullptr;
             e = hipStreamEndCapture(s->capture_stream, &g);
             if (rc == MCRT_OK && e == hipSuccess && g) {
@@ -499,7 +483,7 @@ int launch_or_replay(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStrea
         if (!slot->exec) {  // recording failed: forget it and launch directly
             (void)hipGetLastError();
             slot->n_lanes = 0;
-            return launch_lanes(s, p, n_lanes, stream, marks);
+            return launch_lanes(s, p, n_lanes, stream);
         }
     }
     slot->last_use = s->use_clock;
@@ -531,6 +515,14 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     if (whole.owned_rows <= 0) return MCRT_OK;
     if (cfg->max_bounces > kMaxBounces) return fail(MCRT_ERR_INVALID, "max_bounces above 4000 is not supported (one stack slot per level and sample)");
     const int n_lanes = lane_count(s, *cfg, whole);
+    if (cfg->ao_enabled && cfg->ao_samples > 0 && !s->full_table_tried) {  // the first ambient-occlusion render of this shell
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (!(hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)) {  // (building it launches and waits)
+            s->full_table_tried = true;
+            s->seed_table_full = acquire_full_seed_table(s->device);
+            s->holds_full_table = s->seed_table_full != nullptr;
+        }
+    }
     RenderParams p[kMaxLanes];
     std::memset(p, 0, sizeof p);
     std::vector<int> row_touched[kMaxLanes];
@@ -612,26 +604,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
         }
         return rc;
     }
-    // a lone frame on the device path: every lane's background tiles on a side branch (kernels.h: LaunchMarks)
-    LaunchMarks side_marks[kMaxLanes];
-    bool split = false;
-    {
-        static const int forced = env_tristate("MCRT_BG_SPLIT");
-        split = forced < 0 ? false : forced != 0;
-    }
-    for (int li = 0; li < n_lanes && split; ++li) {
-        Lane& ln = s->lanes[li];
-        if (!ln.side) {
-            HIP_TRY(hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ln.side_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ln.side_join, hipEventDisableTiming));
-        }
-        side_marks[li].side = ln.side;
-        side_marks[li].side_fork = ln.side_fork;
-        side_marks[li].side_join = ln.side_join;
-    }
-    const LaunchMarks* sm = split ? side_marks : nullptr;
-    rc = capturing ? launch_lanes(s, p, n_lanes, stream, sm) : launch_or_replay(s, p, n_lanes, stream, may_record, sm);
+    rc = capturing ? launch_lanes(s, p, n_lanes, stream) : launch_or_replay(s, p, n_lanes, stream, may_record);
     if (rc == MCRT_OK && !capturing) {
         HIP_TRY(hipEventRecord(s->last_done, stream));
         s->last_stream = stream;
@@ -694,6 +667,50 @@ const uint32_t* acquire_seed_table(int device) {
     ++t.users;
     return t.ptr;
 }
+// ---- the table for EVERY seed: mt[397] of all 2^32 seeds, 16 GiB of the device's HBM.  The ambient-occlusion seeds,
+// (unsigned)(P.x * 73856093 + P.y * 19349663 + P.z * 83492791) (raytracer.cpp:122-123), cover the whole 32-bit range, and the
+// 397-step recurrence is over a quarter of the AO stage's cycles (its multiply issues at a quarter of the rate).  Built on
+// a device's first AO render (0.2 s), when the device has the room; MCRT_AO_SEED_TABLE=0 turns it off, mcrt_trim() frees it.
+std::vector<SeedTable> g_full_tables;  // by device (g_seed_mutex)
+const uint32_t* acquire_full_seed_table(int device) {
+    static const bool enabled = [] {
+        const char* e = std::getenv("MCRT_AO_SEED_TABLE");
+        return !e || std::atoi(e) != 0;
+    }();
+    if (!enabled) return nullptr;
+    std::lock_guard<std::mutex> lock(g_seed_mutex);
+    if (g_full_tables.size() <= static_cast<size_t>(device)) g_full_tables.resize(static_cast<size_t>(device) + 1);
+    SeedTable& t = g_full_tables[static_cast<size_t>(device)];
+    if (!t.ptr) {
+        const size_t bytes = static_cast<size_t>(1) << 34;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes * 3) {  // only where it is a small part of what is free
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        uint32_t* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipError_t e = hipSuccess;
+        for (uint32_t part = 0; part < 16u && e == hipSuccess; ++part) e = launch_build_seed_table_range(p, part << 28, 1u << 28, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
+        t.ptr = p;
+    }
+    ++t.users;
+    return t.ptr;
+}
+void release_full_seed_table(int device) {
+    std::lock_guard<std::mutex> lock(g_seed_mutex);
+    if (static_cast<size_t>(device) < g_full_tables.size() && g_full_tables[static_cast<size_t>(device)].users > 0)
+        --g_full_tables[static_cast<size_t>(device)].users;
+}
 void release_seed_table(int device) {
     std::lock_guard<std::mutex> lock(g_seed_mutex);
     if (static_cast<size_t>(device) < g_seed_tables.size() && g_seed_tables[static_cast<size_t>(device)].users > 0)
@@ -701,6 +718,14 @@ void release_seed_table(int device) {
 }
 void free_unused_seed_tables() {  // mcrt_trim
     std::lock_guard<std::mutex> lock(g_seed_mutex);
+    for (size_t d = 0; d < g_full_tables.size(); ++d) {
+        SeedTable& t = g_full_tables[d];
+        if (t.ptr && t.users == 0) {
+            (void)hipSetDevice(static_cast<int>(d));
+            (void)hipFree(t.ptr);
+            t.ptr = nullptr;
+        }
+    }
     for (size_t d = 0; d < g_seed_tables.size(); ++d) {
         SeedTable& t = g_seed_tables[d];
         if (t.ptr && t.users == 0) {
@@ -829,7 +854,6 @@ int create_scene_from_blob(const std::vector<uint8_t>& b, int device, mcrt_scene
         s->device = device;
     }
     s->forced_lanes = 0;
-    s->one_shot = false;
     s->budget = 0;  // a budget halved under memory pressure is not inherited
     s->have_last = false;  // a pooled shell was synchronised when its previous owner let go of it
     s->last_stream = nullptr;
@@ -905,15 +929,12 @@ namespace {
 void destroy_scene_now(mcrt_scene* s) {
     if (!s) return;
     if (s->holds_seed_table) release_seed_table(s->device);
+    if (s->holds_full_table) release_full_seed_table(s->device);
     s->blob.release();  // the other buffers are released by their destructors below
     for (auto& ln : s->lanes) {
         if (ln.stream) (void)hipStreamSynchronize(ln.stream);
         if (ln.done) (void)hipEventDestroy(ln.done);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
-        if (ln.side) (void)hipStreamSynchronize(ln.side);
-        if (ln.side_fork) (void)hipEventDestroy(ln.side_fork);
-        if (ln.side_join) (void)hipEventDestroy(ln.side_join);
-        if (ln.side) (void)hipStreamDestroy(ln.side);
     }
     for (auto& r : s->recorded) {
         if (r.exec) (void)hipGraphExecDestroy(r.exec);
@@ -1210,7 +1231,6 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, void* ou
         // path (1 MB chunks, ~15 GB/s: 2.3 ms per 1080p call instead of 0.8, tools/micro/hostpath.cpp), and
         // for a host-buffer render the download, not the chain of kernels, is the longer part.
         s->forced_lanes = 1;
-        s->one_shot = true;
         rc = one_shot_streams(s);
         if (rc != MCRT_OK) break;
         const Shard mine = make_shard(*cfg, r, n_ranks);
@@ -1442,7 +1462,6 @@ int mcrt_render_rect(const mcrt_scene_desc* desc, const mcrt_config* cfg, const 
     int rc = mcrt_scene_create(desc, device, &s);
     if (rc != MCRT_OK) return rc;
     s->forced_lanes = 1;  // one stream, like every host-buffer entry point (see render_to_host)
-    s->one_shot = true;
     const size_t row_floats = static_cast<size_t>(cfg->width) * 4;
     std::vector<float> host(row_floats * static_cast<size_t>(tile->height));
     hipError_t e = s->frame.reserve(host.size() * 4);

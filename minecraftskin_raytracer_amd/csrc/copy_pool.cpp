@@ -28,7 +28,8 @@ public:
             return;
         }
         std::unique_lock<std::mutex> lock(mu_);
-        cv_idle_.wait(lock, [&] { return pending_ == 0; });  // one job at a time (callers from several threads take turns)
+        cv_idle_.wait(lock, [&] { return !busy_; });  // one job at a time: callers from several threads take turns
+        busy_ = true;  // (a new job may only start once this caller has SEEN its own job complete)
         dst_ = static_cast<char*>(dst), src_ = static_cast<const char*>(src), bytes_ = bytes, parts_ = parts;
         next_ = 1;  // part 0 is the caller's
         pending_ = parts;
@@ -37,8 +38,8 @@ public:
         cv_work_.notify_all();
         run_part(0);
         lock.lock();
-        --pending_;
-        cv_done_.wait(lock, [&] { return pending_ == 0; });
+        if (--pending_ != 0) cv_done_.wait(lock, [&] { return pending_ == 0; });
+        busy_ = false;
         lock.unlock();
         cv_idle_.notify_one();
     }
@@ -92,7 +93,7 @@ private:
     size_t bytes_ = 0;
     int parts_ = 0, next_ = 0, pending_ = 0;
     unsigned long long generation_ = 0;
-    bool stop_ = false;
+    bool stop_ = false, busy_ = false;
 };
 
 

@@ -85,6 +85,8 @@ constexpr uint32_t kSeedWindow = 1u << 25;  // table entries: seed s at index s 
 struct RenderParams {
     const uint8_t* scene;  // flat blob in HBM
     const uint32_t* seed_table;  // kSeedWindow words, or NULL: every hit seeds by the recurrence
+    const uint32_t* seed_table_full;  // mt[397] for EVERY 32-bit seed (16 GiB, built on a device's first ambient-occlusion
+                                      // render: the AO seeds, raytracer.cpp:122-123, cover the whole range), or NULL
     mcrt_config cfg;
     Shard shard;
     int layout;            // MCRT_LAYOUT_*
@@ -113,10 +115,6 @@ struct RenderParams {
     int rect_x, rect_y, rect_w, rect_h;  // rect_w > 0: the launch renders ONE tile, this rectangle (TileRenderer::renderTile for an
                            //    arbitrary Tile, tile_renderer.cpp:71-127: seed rect_y * width + rect_x, pixels in the rectangle's own
                            //    row-major order); the shard is then one tile row of one tile
-    int plan_wg;           // `plan_tiles`: 1 — a workgroup per tile (four waves twist and consume the stream); 0 — a wave per tile
-    int fold_chase;        // 1 — `primary` follows every chain to its end itself (no `chase` launch): the lone-frame form
-    int lit_raygen;        // `lit`: 1 — the ray lanes form their light sample themselves (skip to draws 2j, 2j+1 of the hit's stream);
-                           //    0 — a lane per undecided record forms all S positions, handed over through LDS
 };
 
 Shard make_shard(const mcrt_config& cfg, int first, int step);
@@ -146,10 +144,6 @@ struct LaunchMarks {
     hipEvent_t after_plan = nullptr;
     hipEvent_t* batch_done = nullptr;
     int n_batch_done = 0;
-    // side branch of a lone frame (all three or none): the background tiles render on `side`, forked from the launch
-    // stream by `side_fork` ahead of plan_tiles and joined by `side_join` behind resolve
-    hipStream_t side = nullptr;
-    hipEvent_t side_fork = nullptr, side_join = nullptr;
 };
 hipError_t launch_render(const RenderParams& p, hipStream_t stream, const LaunchMarks* marks = nullptr);
 
@@ -161,6 +155,8 @@ hipError_t launch_assemble_frame(const mcrt_config& cfg, int world, const float*
 hipError_t launch_quantize(const float* rgba, uint8_t* out, size_t n_pixels, hipStream_t stream);
 // fills table[i] = mt[397] of std::mt19937(i - kSeedWindowHalf) for i < kSeedWindow
 hipError_t launch_build_seed_table(uint32_t* table, hipStream_t stream);
+// fills table[s] = mt[397] of std::mt19937(s) for the seeds first .. first + count - 1 (count a multiple of 256)
+hipError_t launch_build_seed_table_range(uint32_t* table, uint32_t first, uint32_t count, hipStream_t stream);
 // host_reciprocals: d_count floats in device memory, 1.0f / d as the host rounds it (what the render kernels get)
 hipError_t launch_probe_div_const(uint32_t d_first, uint32_t d_count, int mode, const float* host_reciprocals, unsigned long long* counts, hipStream_t stream);
 

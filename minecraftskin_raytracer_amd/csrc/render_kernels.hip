@@ -172,15 +172,14 @@ constexpr int kStreamWaves = 4;  // tiles per workgroup
 // the pixels [lo, hi) of a background tile; draw(g) = draw number g of the tile's stream
 template <class DrawFn>
 __device__ __forceinline__ void background_pixels(const SceneView& sc, const RenderParams& p, const TileGeom& tg, float4* __restrict__ out_frame,
-                                                  uchar4* __restrict__ out8, unsigned lo, unsigned hi, int lane, DrawFn&& draw,
-                                                  unsigned nthreads = 64u) {
+                                                  uchar4* __restrict__ out8, unsigned lo, unsigned hi, int lane, DrawFn&& draw) {
     const mcrt_config& cfg = p.cfg;
     const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
     const unsigned dd = static_cast<unsigned>(p.draws_per_sample);
     const FrameDiv fd(p);
     const float inv_spp = 1.0f / static_cast<float>(spp);
     const UDiv by_w(static_cast<unsigned>(tg.w));
-    for (unsigned pix = lo + static_cast<unsigned>(lane); pix < hi; pix += nthreads) {
+    for (unsigned pix = lo + static_cast<unsigned>(lane); pix < hi; pix += 64u) {
         const unsigned uly = by_w.div(pix);
         const int ly = static_cast<int>(uly);
         const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
@@ -608,205 +607,6 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// plan_tiles, a WORKGROUP per tile (round 3).  With a wave per tile the kernel's duration was the serial work of ONE
-// wave — 13 twists of 11 rounds each plus 16 rounds of background pixels at 1080p / 4 spp — at two waves per SIMD
-// (2 040 tiles on 1 024 SIMDs): 46 us, a fifth of the frame's chain.  Four waves per tile: a twist is three
-// phases of one round each (new word k needs new word k - 227: 227 + 227 + 170 words) with a barrier behind each;
-// the stream is produced in rounds of kPlanTwists twists whose words stay in LDS side by side — the buffer IS the
-// sequence of engine states — and are consumed by all 256 threads: written out as uniform floats (a tile meshes
-// can touch) or turned into the tile's background pixels, a thread per SAMPLE (the pixel's samples are added in
-// order by a lane shuffle when spp divides the wave, through LDS otherwise).
-// `mode` lets a lone frame run its background tiles BESIDE the chain of the tiles that hold the figure
-// (launch_render): kPlanTouched plans every tile and produces the touched tiles' draws, kPlanBackground renders
-// the background tiles and touches nothing else (no counters, no masks), kPlanAll does both.
-// ---------------------------------------------------------------------------------------------
-#ifndef MCRT_PLAN_TWISTS
-#define MCRT_PLAN_TWISTS 7
-#endif
-constexpr int kPlanTwists = MCRT_PLAN_TWISTS;
-constexpr int kPlanAll = 0, kPlanTouched = 1, kPlanBackground = 2;
-
-// One twist of the 624-word state `o` into `n` by the workgroup's 256 threads
-__device__ __forceinline__ void twist_block(const uint32_t* o, uint32_t* n, int tid) {
-    if (tid < 227) n[tid] = mt_twist(o[tid], o[tid + 1], o[tid + 397]);
-    __syncthreads();
-    if (tid < 227) {
-        const int k = 227 + tid;
-        n[k] = mt_twist(o[k], o[k + 1], n[k - 227]);
-    }
-    __syncthreads();
-    if (tid < 170) {
-        const int k = 454 + tid;
-        n[k] = mt_twist(o[k], (k == 623) ? n[0] : o[k + 1], n[k - 227]);
-    }
-    __syncthreads();
-}
-
-// The tile's stream of `total` draws in rounds of up to kPlanTwists twists.  Segment 0 of `st` holds the state before
-// the round — the seeded state, later the previous round's last segment, i.e. the 624 draws before this round's —
-// segments 1 .. the round's new words.  consume(done, m): draws [done, done + m) of the tile are the (untempered)
-// words st[624 .. 624 + m); draw g < done (g >= done - 624, done > 0) is st[624 - (done - g)].  Collective.
-template <class Consume>
-__device__ __forceinline__ void tile_stream_block(const uint32_t* __restrict__ seeded, uint32_t* st, unsigned long long total, Consume&& consume) {
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 624; e += kBlock) st[e] = seeded[e];
-    __syncthreads();
-    for (unsigned long long done = 0; done < total;) {  // uniform
-        const unsigned long long left = total - done;
-        const int twists = left >= static_cast<unsigned long long>(kPlanTwists) * 624ull ? kPlanTwists : static_cast<int>((left + 623ull) / 624ull);
-        for (int i = 0; i < twists; ++i) twist_block(st + i * 624, st + (i + 1) * 624, tid);
-        const unsigned long long made = static_cast<unsigned long long>(twists) * 624ull;
-        consume(done, static_cast<unsigned>(left < made ? left : made));
-        done += made;
-        if (done < total) {  // the round's last segment becomes segment 0 (twists == kPlanTwists here)
-            __syncthreads();  // consume has read the segments
-            uint32_t v[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int e = tid + kBlock * i;
-                v[i] = e < 624 ? st[kPlanTwists * 624 + e] : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int e = tid + kBlock * i;
-                if (e < 624) st[e] = v[i];
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// The pixels [lo, hi) of a background tile by the workgroup, a thread per SAMPLE: jitter(g, jx, jy) = the two jitter draws
-// of the sample whose draws start at number g of the tile's stream.  The pixel's samples are added in sample order
-// (tile_renderer.cpp:116-124): by lane shuffles when spp divides the wave (the samples of a pixel are neighbouring lanes),
-// through s_col otherwise.  spp >= 2 and spp * draws <= 24 (bg_in_plan).  Collective.
-template <class JitterFn>
-__device__ __forceinline__ void background_block(const SceneView& sc, const RenderParams& p, const TileGeom& tg, float4* __restrict__ out_frame,
-                                                 uchar4* __restrict__ out8, unsigned lo, unsigned hi, float4* s_col, JitterFn&& jitter) {
-    const mcrt_config& cfg = p.cfg;
-    const unsigned spp = static_cast<unsigned>(cfg.samples_per_pixel);
-    const unsigned dd = static_cast<unsigned>(p.draws_per_sample);
-    const FrameDiv fd(p);
-    const float inv_spp = 1.0f / static_cast<float>(spp);
-    const UDiv by_w(static_cast<unsigned>(tg.w)), by_spp(spp);
-    const unsigned tid = threadIdx.x;
-    auto sample_colour = [&](unsigned pix, unsigned sidx) __attribute__((always_inline)) {
-        const unsigned uly = by_w.div(pix);
-        const float fx = static_cast<float>(tg.x + static_cast<int>(pix - uly * static_cast<unsigned>(tg.w)));
-        const float fy = static_cast<float>(tg.y + static_cast<int>(uly));
-        float jx, jy;
-        jitter((static_cast<unsigned long long>(pix) * spp + sidx) * dd, jx, jy);
-        return background(sc, cfg, fd.u(fx + jx), fd.v(fy + jy));  // tile_renderer.cpp:111-114
-    };
-    auto put = [&](unsigned pix, float ar, float ag, float ab, float aa) __attribute__((always_inline)) {
-        const unsigned uly = by_w.div(pix);
-        const int ly = static_cast<int>(uly);
-        const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
-        const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
-        store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx), make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp));
-    };
-    if ((spp & (spp - 1u)) == 0u && spp <= 64u) {
-        // the samples of a pixel sit in spp neighbouring lanes of one wave (256 and the range's ends are multiples of spp)
-        const unsigned s_lo = lo * spp, s_hi = hi * spp;
-        const int lane = static_cast<int>(tid & 63u);
-        const int first_lane = lane & ~static_cast<int>(spp - 1u);
-        for (unsigned base = s_lo; base < s_hi; base += kBlock) {  // uniform
-            const unsigned t = base + tid;
-            const unsigned pix = by_spp.div(t), sidx = t - pix * spp;
-            C4 c{0.0f, 0.0f, 0.0f, 0.0f};
-            if (t < s_hi) c = sample_colour(pix, sidx);
-            float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
-            for (unsigned s = 0; s < spp; ++s) {  // every lane of the wave takes part in the shuffles
-                ar += __shfl(c.r, first_lane + static_cast<int>(s));
-                ag += __shfl(c.g, first_lane + static_cast<int>(s));
-                ab += __shfl(c.b, first_lane + static_cast<int>(s));
-                aa += __shfl(c.a, first_lane + static_cast<int>(s));
-            }
-            if (t < s_hi && sidx == 0u) put(pix, ar, ag, ab, aa);
-        }
-        return;
-    }
-    const unsigned chunk_px = static_cast<unsigned>(kBlock) / spp;
-    for (unsigned p0 = lo; p0 < hi; p0 += chunk_px) {  // uniform
-        const unsigned npx = min(chunk_px, hi - p0);
-        if (tid < npx * spp) {
-            const unsigned q = by_spp.div(tid);
-            const C4 c = sample_colour(p0 + q, tid - q * spp);
-            s_col[tid] = make_float4(c.r, c.g, c.b, c.a);
-        }
-        __syncthreads();
-        if (tid < npx) {
-            float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
-            for (unsigned s = 0; s < spp; ++s) {
-                const float4 c = s_col[tid * spp + s];
-                ar += c.x, ag += c.y, ab += c.z, aa += c.w;
-            }
-            put(p0 + tid, ar, ag, ab, aa);
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void plan_tiles_wg_kernel(const uint8_t* __restrict__ scene_blob, const uint32_t* __restrict__ tile_rng,
-                                                               float* __restrict__ tile_draws, float4* __restrict__ out_frame,
-                                                               uchar4* __restrict__ out8, const RenderParams p, const int tile_base, const int mode) {
-    __shared__ uint32_t s_st[(kPlanTwists + 1) * 624];
-    __shared__ float4 s_col[kBlock];
-    __shared__ unsigned long long s_mask;
-    __shared__ uint32_t s_ord;
-    const int tid = threadIdx.x;
-    const int t = static_cast<int>(blockIdx.x);  // the grid is the batch's tiles
-    const int tile = tile_base + t;
-    const TileGeom tg = tile_of(p, tile);
-    const SceneView sc = view_of(scene_blob);
-    if (tid < 64) {  // the first wave: a lane per mesh
-        const unsigned long long m = tile_mesh_mask(sc, p, tg, tid);
-        if (tid == 0) {
-            s_mask = m;
-            s_ord = (mode != kPlanBackground) ? plan_touched_tile(p, tg, tile, m) : ~0u;
-        }
-    }
-    __syncthreads();
-    const unsigned long long mask = s_mask;
-    const uint32_t ord = s_ord;
-    const mcrt_config& cfg = p.cfg;
-    const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
-    const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
-    const unsigned long long total = static_cast<unsigned long long>(npix) * static_cast<unsigned>(spp) * static_cast<unsigned>(p.draws_per_sample);
-    const uint32_t* seeded = tile_rng + static_cast<size_t>(tile) * 624;
-    auto draws_to = [&](float* __restrict__ dst) __attribute__((always_inline)) {  // the tile's whole stream as uniform floats
-        tile_stream_block(seeded, s_st, total, [&](unsigned long long done, unsigned m) __attribute__((always_inline)) {
-            for (unsigned e = static_cast<unsigned>(tid); e < m; e += kBlock) dst[done + e] = mt_to_unit(mt_temper(s_st[624u + e]));
-        });
-    };
-    const size_t stride = p.ws.draws_stride;
-    if (!p.bg_in_plan) {  // every tile's draws to HBM; `primary` renders the background tiles (those of one colour need no draws)
-        float4 unused;
-        if (mode != kPlanBackground && p.draws_per_sample > 0 && !(mask == 0ull && constant_background(sc, p, tg, unused))) draws_to(tile_draws + static_cast<size_t>(t) * stride);
-    } else if (mask != 0ull) {  // a tile meshes can touch: its draws, at its touched-tile number
-        if (mode != kPlanBackground && p.draws_per_sample > 0 && ord != ~0u) draws_to(tile_draws + static_cast<size_t>(ord) * stride);
-    } else if (mode == kPlanTouched) {
-        return;
-    } else if (float4 pixel; constant_background(sc, p, tg, pixel)) {  // background tile of one colour: no draws, no samples
-        fill_tile(p, tg, out_frame, out8, pixel, static_cast<unsigned>(tid), static_cast<unsigned>(kBlock));
-    } else if (spp > 1) {  // background tile, jittered samples: rendered from the draws in LDS
-        const unsigned long long per_pixel = static_cast<unsigned long long>(spp) * static_cast<unsigned>(p.draws_per_sample);
-        unsigned pixels_done = 0;
-        tile_stream_block(seeded, s_st, total, [&](unsigned long long done, unsigned m) __attribute__((always_inline)) {
-            const unsigned complete = static_cast<unsigned>((done + m) / per_pixel);  // pixels whose draws all exist; the first of them starts within the 624 draws before `done`
-            background_block(sc, p, tg, out_frame, out8, pixels_done, complete, s_col, [&](unsigned long long g, float& jx, float& jy) __attribute__((always_inline)) {
-                const uint32_t* w = s_st + (624 + static_cast<int>(static_cast<long long>(g) - static_cast<long long>(done)));
-                jx = mt_to_unit(mt_temper(w[0]));
-                jy = mt_to_unit(mt_temper(w[1]));
-            });
-            pixels_done = complete;
-        });
-    } else {  // background tile, one centred sample per pixel: no draws at all
-        background_pixels(sc, p, tg, out_frame, out8, 0u, npix, tid, [](unsigned long long) __attribute__((always_inline)) { return 0.5f; }, static_cast<unsigned>(kBlock));
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // primary: persistent workgroups; touched units first, then the background tiles.  A sample's draws
 // sit in tile_draws at ((pixel in tile) * spp + sample) * draws_per_sample.
 // ---------------------------------------------------------------------------------------------
@@ -930,48 +730,11 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restri
                         ws.end[root] = chain_code(1, false);  // bounced ray missed → flat background (raytracer.cpp:94-102)
                 }
                 int survivors = 0;
-                int srank = block_rank(next_hit, s_wcnt, survivors);
+                const int srank = block_rank(next_hit, s_wcnt, survivors);
                 if (survivors > 0) {  // uniform
                     if (tid == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep1], static_cast<uint32_t>(survivors));
                     __syncthreads();
                     if (next_hit) push_record(ws, posed, ws.cap + s_out_base + static_cast<uint32_t>(srank), nray, nhit, root, 1, true);
-                }
-                // fold_chase (a lone frame): the chains are followed to their end right here, packed on the block's first
-                // lanes turn after turn (~10 % go on per turn) — `chase` as a launch of its own is ~30 us of the frame's
-                // dependent chain for 3 % of its work.  All deep records then come from this kernel (one counter).
-                if (p.fold_chase) {
-                    int level = 1;  // depth of the records the survivors have just become
-                    while (survivors > 0) {  // uniform
-                        if (level >= cfg.max_bounces) {  // no reflection at the last level (raytracer.cpp:133)
-                            if (next_hit) ws.end[root] = chain_code(level + 1, true);
-                            break;
-                        }
-                        if (next_hit) {  // (the reads of the previous turn lie behind block_rank's barriers)
-                            s_bd[srank] = make_float4(nray.d.x, nray.d.y, nray.d.z, __uint_as_float(root));
-                            s_bp[srank] = make_float4(nhit.p.x, nhit.p.y, nhit.p.z, 0.0f);
-                            s_bn[srank] = make_float4(nhit.n.x, nhit.n.y, nhit.n.z, 0.0f);
-                        }
-                        __syncthreads();
-                        const int n = survivors;
-                        next_hit = false;
-                        if (tid < n) {
-                            const float4 bd = s_bd[tid], bp = s_bp[tid], bn = s_bn[tid];
-                            root = __float_as_uint(bd.w);
-                            nray = reflect_ray(mk(bd.x, bd.y, bd.z), mk(bp.x, bp.y, bp.z), mk(bn.x, bn.y, bn.z));
-                            nhit = hit_scene<true>(sc, nray, ~0ull);
-                            if (nhit.hit)
-                                next_hit = true;
-                            else
-                                ws.end[root] = chain_code(level + 1, false);
-                        }
-                        ++level;
-                        srank = block_rank(next_hit, s_wcnt, survivors);
-                        if (survivors > 0) {  // uniform
-                            if (tid == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep1], static_cast<uint32_t>(survivors));
-                            __syncthreads();
-                            if (next_hit) push_record(ws, posed, ws.cap + s_out_base + static_cast<uint32_t>(srank), nray, nhit, root, level, true);
-                        }
-                    }
                 }
                 __syncthreads();  // s_bd .. s_out_base are reused by the next chunk
             }
@@ -1366,8 +1129,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_dyn + p.lit_lds_offset);  // 16-aligned
     float* s_pos = reinterpret_cast<float*>(s_cand + round);
     const uint32_t pass = static_cast<uint32_t>(p.lit_pass);  // records whose sample positions fit the LDS area at once
-    uint32_t* s_mt = reinterpret_cast<uint32_t*>(s_pos);  // lit_raygen: mt[397] of the undecided records' engines instead of positions
-    uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + (p.lit_raygen ? static_cast<size_t>(round) : static_cast<size_t>(pass) * pairs_per_hit * 3));
+    uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + static_cast<size_t>(pass) * pairs_per_hit * 3);
     uint32_t* s_und = s_lit + round;  // the round's undecided records, packed
     const V3 lpos = ld3(scg.hdr->light_pos);
     const float lradius = scg.hdr->light_radius;
@@ -1423,7 +1185,6 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                 const uint32_t nu = min(pass, n_und - u0);
                 if (u0) __syncthreads();  // the previous pass's rays have read the positions
                 // ---- phase A2: a lane per undecided record — its mt19937 stream and the S disk sample positions
-                // (lit_raygen: only the engine's sequential part, mt[397] of the seed; the ray lanes draw for themselves)
                 if (mode == SHADOW_SOFT && threadIdx.x < nu) {
                     const RecordGeom g = load_geom(ws, posed, base + s_und[u0 + threadIdx.x]);
                     const V3 P = g.p;
@@ -1432,12 +1193,13 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                     const uint32_t slot = seed + kSeedWindowHalf;  // wraps: the window is centred on seed 0
                     if (p.seed_table && slot < kSeedWindow)
                         rng.seed_known(seed, p.seed_table[slot]);  // mt[397] of this seed, from the device's table
+                    else if (p.seed_table_full)
+                        rng.seed_known(seed, p.seed_table_full[seed]);  // (a scene at another scale: its seeds leave the window)
                     else
                         rng.seed(seed);  // the 397-step recurrence
-                    if (p.lit_raygen) s_mt[threadIdx.x] = rng.hi;
                     const LightFrame frame = light_frame(scg, P);
                     float* dst = s_pos + static_cast<size_t>(threadIdx.x) * 3 * S;
-                    for (int i = 0; i < S && !p.lit_raygen; ++i) {
+                    for (int i = 0; i < S; ++i) {
                         const float d0 = rng.uniform();
                         const float d1 = rng.uniform();
                         const V3 t = light_sample_on_frame(scg, frame, d0, d1);
@@ -1459,18 +1221,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                         V3 P, N;
                         load_point_normal(ws, posed, base + k, P, N);
                         if (mode == SHADOW_HARD) N = normalize(N);
-                        if (mode == SHADOW_SOFT && p.lit_raygen) {
-                            // light sample q % S of the record: draws 2i, 2i + 1 of its engine (shading.cpp:46-53), formed by
-                            // this lane — the engine's sequential part came from phase A2, the skip to draw 2i costs 2i steps
-                            // of two multiply-adds, and the S double-precision sin/cos of a hit run in S lanes instead of one
-                            const uint32_t jj = q / pairs_per_hit, i = q - jj * pairs_per_hit;
-                            MtShort rng;
-                            rng.seed_known(shadow_seed(P, static_cast<int>(__float_as_uint(ws.q_d[0][base + k].w) & 0xffu)), s_mt[jj]);
-                            for (uint32_t sk = 0; sk < 2u * i; ++sk) rng.skip();
-                            const float d0 = rng.uniform();
-                            const float d1 = rng.uniform();
-                            visible = !in_shadow_masked(sc, P, N, light_sample_on_frame(scg, light_frame(scg, P), d0, d1), s_cand[k]);
-                        } else if (mode == SHADOW_SOFT)
+                        if (mode == SHADOW_SOFT)
                             visible = !in_shadow_masked(sc, P, N, ld3(s_pos + static_cast<size_t>(q) * 3), s_cand[k]);
                         else
                             visible = !in_shadow_inline(sc, P, N, lpos);
@@ -1575,7 +1326,11 @@ __global__ __launch_bounds__(kBlock, MCRT_AO_WAVES) void ao_kernel(const uint8_t
             const unsigned long long cand = s_mask[k];
             const V3 O = P + N * 1e-3f;
             MtShort rng;
-            rng.seed(ao_seed(P));
+            const uint32_t seed = ao_seed(P);
+            if (p.seed_table_full)
+                rng.seed_known(seed, p.seed_table_full[seed]);  // mt[397] of this seed: one load instead of the 397-step recurrence
+            else
+                rng.seed(seed);
             uint32_t occluded = 0;
             for (int i = 0; i < A; ++i) {
                 const float r1 = rng.uniform();
@@ -1798,6 +1553,12 @@ __global__ __launch_bounds__(256) void seed_table_kernel(uint32_t* __restrict__ 
     if (i < kSeedWindow) table[i] = MtShort::word397(i - kSeedWindowHalf);
 }
 
+// the full table: entry s = mt[397] of std::mt19937(s), for the seeds first + (this thread)
+__global__ __launch_bounds__(256) void seed_table_range_kernel(uint32_t* __restrict__ table, uint32_t first) {
+    const uint32_t s = first + blockIdx.x * 256u + threadIdx.x;
+    table[s] = MtShort::word397(s);
+}
+
 __global__ void quantize_kernel(const float4* rgba, uchar4* out, size_t n) {  // image_writer.cpp:18-22
     size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2004,13 +1765,8 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
         if (pass > static_cast<size_t>(kBlock)) pass = kBlock;
         if (pass < 1) pass = 1;
         p.lit_round = kBlock;
-        if (p.lit_raygen) {  // no positions in LDS: one word per undecided record, every undecided record of a round in one pass
-            pass = kBlock;
-            p.lit_lds_bytes = static_cast<int>(static_cast<size_t>(kBlock) * 4 + static_cast<size_t>(kBlock) * 16);
-        } else {
-            p.lit_lds_bytes = static_cast<int>(pass * 12 * pairs + static_cast<size_t>(kBlock) * 16);
-        }
         p.lit_pass = static_cast<int>(pass);
+        p.lit_lds_bytes = static_cast<int>(pass * 12 * pairs + static_cast<size_t>(kBlock) * 16);
         p.lit_lds_offset = static_cast<int>((scene_table_bytes(p) + 15) & ~static_cast<size_t>(15));
     }
     const int owned = p.shard.owned_rows;
@@ -2104,7 +1860,7 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : kQueueGrid;
     }();
-    if (levels >= 2 && !p.fold_chase)  // the chains below the level-1 records `primary` found (maxBounces = 0: it has marked the chains already)
+    if (levels >= 2)  // the chains below the level-1 records `primary` found (maxBounces = 0: it has marked the chains already)
         hipLaunchKernelGGL(chase_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
     if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
@@ -2136,24 +1892,8 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
         // kCounterWords - 1 words were two
         hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 4) * 4, stream);
         if (e != hipSuccess) return e;
-        // A lone frame (side branch given, one pass): the background tiles render BESIDE the chain of the tiles that hold
-        // the figure — the chain starts with those tiles' planning alone, and the background's VALU work fills the
-        // gaps of its latency-bound kernels.  Forked from `stream` here, joined behind `resolve`.
-        const bool split = p.plan_wg && p.bg_in_plan && marks && marks->side && p.rows_per_batch >= p.shard.owned_rows;
-        if (!p.plan_wg) {
-            hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
-                               p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
-        } else if (!split) {
-            hipLaunchKernelGGL(plan_tiles_wg_kernel, dim3(batch_tiles), dim3(kBlock), 0, stream, p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, kPlanAll);
-        } else {
-            e = hipEventRecord(marks->side_fork, stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(marks->side, marks->side_fork, 0);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(plan_tiles_wg_kernel, dim3(batch_tiles), dim3(kBlock), 0, stream, p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, kPlanTouched);
-            hipLaunchKernelGGL(plan_tiles_wg_kernel, dim3(batch_tiles), dim3(kBlock), 0, marks->side, p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, kPlanBackground);
-            e = hipEventRecord(marks->side_join, marks->side);
-            if (e != hipSuccess) return e;
-        }
+        hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
+                           p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
         if (marks && marks->after_plan && r0 == 0) {
             e = hipEventRecord(marks->after_plan, stream);
             if (e != hipSuccess) return e;
@@ -2171,10 +1911,6 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
         }
         const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
         hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, p.scene, out, out8, p);
-        if (split) {
-            e = hipStreamWaitEvent(stream, marks->side_join, 0);
-            if (e != hipSuccess) return e;
-        }
         const int batch = r0 / p.rows_per_batch;
         if (marks && batch < marks->n_batch_done) {
             e = hipEventRecord(marks->batch_done[batch], stream);
@@ -2218,6 +1954,12 @@ hipError_t launch_quantize(const float* rgba, uint8_t* out, size_t n_pixels, hip
 
 hipError_t launch_build_seed_table(uint32_t* table, hipStream_t stream) {
     hipLaunchKernelGGL(seed_table_kernel, dim3(kSeedWindow / 256u), dim3(256), 0, stream, table);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_seed_table_range(uint32_t* table, uint32_t first, uint32_t count, hipStream_t stream) {
+    if (count == 0u || (count & 255u)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seed_table_range_kernel, dim3(count / 256u), dim3(256), 0, stream, table, first);
     return hipGetLastError();
 }
 
