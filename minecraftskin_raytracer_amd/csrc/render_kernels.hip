@@ -64,9 +64,9 @@ using namespace rt;
 constexpr int kBlock = 256;
 constexpr int kChunk = 256;        // work items per chunk: one per thread
 #ifndef MCRT_PRIMARY_GRID
-#define MCRT_PRIMARY_GRID 1024
+#define MCRT_PRIMARY_GRID 1280
 #endif
-constexpr int kPrimaryGrid = MCRT_PRIMARY_GRID; // persistent primary workgroups (4 per CU)
+constexpr int kPrimaryGrid = MCRT_PRIMARY_GRID; // persistent primary workgroups (5 per CU: the kernel is built for 5 waves per SIMD)
 constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
 
 // n / d for a divisor that is the same for the whole wave: a shift when it is a power of two (tile widths of 32,
@@ -169,7 +169,7 @@ __device__ __forceinline__ void store_pixel(float4* __restrict__ out_frame, ucha
 // barriers per 624 draws, ~60 us of the 1080p / 4 spp frame, milliseconds at 64 spp.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kStreamWaves = 4;  // tiles per workgroup
-// the pixels [lo, hi) of a background tile; draw(g) = draw number g of the tile's stream
+// the pixels [lo, hi) of a background tile; draw(g, jx, jy) = draws number g, g + 1 of the tile's stream (g even)
 template <class DrawFn>
 __device__ __forceinline__ void background_pixels(const SceneView& sc, const RenderParams& p, const TileGeom& tg, float4* __restrict__ out_frame,
                                                   uchar4* __restrict__ out8, unsigned lo, unsigned hi, int lane, DrawFn&& draw) {
@@ -184,14 +184,11 @@ __device__ __forceinline__ void background_pixels(const SceneView& sc, const Ren
         const int ly = static_cast<int>(uly);
         const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
         const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
-        const unsigned long long g0 = static_cast<unsigned long long>(pix) * static_cast<unsigned>(spp) * dd;
+        const unsigned g0 = pix * static_cast<unsigned>(spp) * dd;  // (a tile's stream is shorter than 2^32 draws: plan_workspace)
         float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
         for (int sidx = 0; sidx < spp; ++sidx) {
             float jx = 0.5f, jy = 0.5f;
-            if (spp > 1) {
-                jx = draw(g0 + static_cast<unsigned>(sidx) * dd);
-                jy = draw(g0 + static_cast<unsigned>(sidx) * dd + 1u);
-            }
+            if (spp > 1) draw(g0 + static_cast<unsigned>(sidx) * dd, jx, jy);  // the sample's two jitter draws: one aligned pair of the stream
             const C4 c = background(sc, cfg, fd.u(fx + jx), fd.v(fy + jy));  // tile_renderer.cpp:111-114
             ar += c.r;
             ag += c.g;
@@ -263,8 +260,8 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
                                                  const TileGeom& tg, int tile, uint32_t* st, int lane) {
     const int spp = p.cfg.samples_per_pixel > 1 ? p.cfg.samples_per_pixel : 1;
     const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
-    const unsigned long long per_pixel = static_cast<unsigned long long>(spp) * p.draws_per_sample;
-    const unsigned long long total = npix * per_pixel;
+    const unsigned per_pixel = static_cast<unsigned>(spp) * static_cast<unsigned>(p.draws_per_sample);
+    const unsigned total = npix * per_pixel;  // < 2^32 - 2^16 (plan_workspace refuses longer streams): 32-bit index arithmetic throughout
     const uint32_t* src = tile_rng + static_cast<size_t>(tile) * 624;
     for (int e = lane; e < 624; e += 64) st[e] = src[e];
     auto wave_sync = [&]() __attribute__((always_inline)) {
@@ -274,7 +271,7 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
     wave_sync();
     int cur = 0;
     unsigned pixels_done = 0;
-    for (unsigned long long done = 0; done < total; done += 624) {
+    for (unsigned done = 0; done < total; done += 624u) {
         const uint32_t* o = st + cur * 624;
         uint32_t* n = st + (cur ^ 1) * 624;
         // mt19937 twist: new[k] from old[k], old[k+1] and old[k+397] (= new[k-227] once k >= 227); the
@@ -298,8 +295,8 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
         }
         wave_sync();
         cur ^= 1;
-        const unsigned long long left = total - done;
-        const int m = left < 624ull ? static_cast<int>(left) : 624;
+        const unsigned left = total - done;
+        const int m = left < 624u ? static_cast<int>(left) : 624;
         if (dst) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
@@ -311,15 +308,18 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
             // go in whole rounds of 64 (a twist completes only 624 / (2 spp) of them — 78 at 4 spp — and a
             // partial round costs as much as a full one); the rest waits for the next twist, except those
             // whose draws reach back into o, which that twist overwrites.
-            const unsigned complete = static_cast<unsigned>((done + static_cast<unsigned long long>(m)) / per_pixel);
-            const unsigned must_end = min(complete, static_cast<unsigned>((done + per_pixel - 1ull) / per_pixel));  // first draw before `done`
+            const unsigned complete = (done + static_cast<unsigned>(m)) / per_pixel;
+            const unsigned must_end = min(complete, (done + per_pixel - 1u) / per_pixel);  // first draw before `done`
             const unsigned pending = complete - pixels_done;
-            unsigned take = (done + 624ull >= total) ? pending : (pending / 64u) * 64u;
+            unsigned take = (done + 624u >= total) ? pending : (pending / 64u) * 64u;
             if (pixels_done + take < must_end) take = must_end - pixels_done;
             if (take > 0u) {
-                background_pixels(sc, p, tg, out_frame, out8, pixels_done, pixels_done + take, lane, [&](unsigned long long g) __attribute__((always_inline)) {
-                    const uint32_t raw = (g >= done) ? n[g - done] : o[g + 624ull - done];
-                    return mt_to_unit(mt_temper(raw));
+                // (g and done are even: the pair is 8-byte aligned in either buffer — one LDS read instead of two, half the
+                // cycles of the 8-lanes-per-bank stride a lane per pixel reads the stream with)
+                background_pixels(sc, p, tg, out_frame, out8, pixels_done, pixels_done + take, lane, [&](unsigned g, float& jx, float& jy) __attribute__((always_inline)) {
+                    const uint2 w = *reinterpret_cast<const uint2*>((g >= done) ? n + (g - done) : o + (g + 624u - done));
+                    jx = mt_to_unit(mt_temper(w.x));
+                    jy = mt_to_unit(mt_temper(w.y));
                 });
                 pixels_done += take;
                 wave_sync();  // the next twist overwrites o
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
                                                                        float* __restrict__ tile_draws, float4* __restrict__ out_frame,
                                                                        uchar4* __restrict__ out8, const RenderParams p,
                                                                        const int tile_base, const int n_tiles) {
-    __shared__ uint32_t s_state[kStreamWaves][2 * 624];
+    __shared__ __align__(16) uint32_t s_state[kStreamWaves][2 * 624];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = static_cast<int>(blockIdx.x) * kStreamWaves + wave;
     if (t >= n_tiles) return;  // wave-uniform; there is no workgroup barrier in this kernel
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
         tile_stream_wave(sc, tile_rng, nullptr, out_frame, out8, p, tg, tile, s_state[wave], lane);
     } else {  // background tile, one centred sample per pixel: no draws at all
         background_pixels(sc, p, tg, out_frame, out8, 0u, static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h), lane,
-                          [](unsigned long long) __attribute__((always_inline)) { return 0.5f; });
+                          [](unsigned, float&, float&) __attribute__((always_inline)) {});
     }
 }
 
@@ -610,8 +610,13 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
 // primary: persistent workgroups; touched units first, then the background tiles.  A sample's draws
 // sit in tile_draws at ((pixel in tile) * spp + sample) * draws_per_sample.
 // ---------------------------------------------------------------------------------------------
+// 5 waves per SIMD (96 VGPRs, four of them spilled) instead of the 4 the unconstrained build settles at (105 VGPRs): same-box
+// A/B +1.5 % at four frames in flight and, with 1280 workgroups, -8 us for one frame alone (profiles/r03_experiments)
+#ifndef MCRT_PRIMARY_WAVES
+#define MCRT_PRIMARY_WAVES 5
+#endif
 template <int kView>
-__global__ __launch_bounds__(kBlock) void primary_kernel(const uint8_t* __restrict__ scene_blob,
+__global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(const uint8_t* __restrict__ scene_blob,
                                                          const float* __restrict__ tile_draws,
                                                          float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p,
                                                          const int tile_base, const int n_tiles) {
@@ -1812,7 +1817,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     size_t cap_tiles = owned > 0 ? fullest(rows) : 0;
     if (cap_tiles < 1) cap_tiles = 1;
     p.rows_per_batch = rows;
-    if (tile_slots == 0 || cap_tiles > index_limit / tile_slots || draws_stride > 0xfffffff0ull)
+    if (tile_slots == 0 || cap_tiles > index_limit / tile_slots || draws_stride > 0xffff0000ull)
         p.rows_per_batch = 0;  // one tile (row) alone exceeds the 32-bit index ranges: refused by the caller
     const size_t cap = p.rows_per_batch ? cap_tiles * tile_slots : 1;
     const size_t rec_cap = cap * recs;

@@ -21,6 +21,8 @@ CASES = {
     "tiny": (lambda: scenes.skin_scene("S64", 0), dict(width=64, height=64, maxBounces=4, samplesPerPixel=4)),
     "8k": (lambda: scenes.skin_scene("S32", 0), dict(width=7680, height=4320, maxBounces=8, samplesPerPixel=64)),
     "4k": (lambda: scenes.skin_scene("S64", 0), dict(width=3840, height=2160, maxBounces=8, samplesPerPixel=16)),
+    "4k_b4": (lambda: scenes.skin_scene("S64", 0), dict(width=3840, height=2160, maxBounces=4, samplesPerPixel=4)),
+    "c256": (lambda: scenes.skin_scene("S64", 0), dict(width=256, height=256, maxBounces=1, samplesPerPixel=1)),
 }
 name = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
