@@ -110,6 +110,8 @@ struct RenderParams {
     int flat;              // 1: flat pipeline (all levels' records shaded at once); 0: general variants, one launch set per level
     float inv_width, inv_height;  // 1.0f / width, 1.0f / height (correctly rounded: formed on the host)
     int div_frame;         // 1: width and height lie in rt::div_frame's verified range (rt_core.h)
+    int inside_fast;       // shadow / AO rays: 1 — a candidate whose box holds the ray's origin strictly inside takes
+                           //    rt::mesh_candidate_inside (the exit face alone); 0 (MCRT_INSIDE_FAST=0) — the general routine
     int bundle_decisions;  // `lit`: 1 — a hit whose whole bundle of shadow rays is decided (rt::bundle_decide) draws no light
                            //    samples and traces no rays; 0 (MCRT_BUNDLE_DECISIONS=0) — every hit's rays are traced
     int rect_x, rect_y, rect_w, rect_h;  // rect_w > 0: the launch renders ONE tile, this rectangle (TileRenderer::renderTile for an

@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
 #endif
 template <int kView>
 __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
-    extern __shared__ __align__(16) unsigned char s_dyn[];  // [scene tables][masks: lit_round][positions: lit_pass x S x 3 floats][lit counts: lit_round][undecided list: lit_round]
+    extern __shared__ __align__(16) unsigned char s_dyn[];  // [scene tables][candidate masks: lit_round][inside masks: lit_round][positions: lit_pass x S x 3 floats][lit counts: lit_round][undecided list: lit_round]
     __shared__ int s_wcnt[kBlock / 64];
     MCRT_HOOK_LIT_SHARED
     const SceneView scg = view_of(scene_blob);
@@ -1132,7 +1132,8 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const bool pow2 = (pairs_per_hit & (pairs_per_hit - 1u)) == 0u && pairs_per_hit <= 64u;
     const uint32_t round = static_cast<uint32_t>(p.lit_round);
     unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_dyn + p.lit_lds_offset);  // 16-aligned
-    float* s_pos = reinterpret_cast<float*>(s_cand + round);
+    unsigned long long* s_ins = s_cand + round;  // of those, the boxes that hold the record's ray origin strictly inside (rt::mesh_candidate_inside)
+    float* s_pos = reinterpret_cast<float*>(s_ins + round);
     const uint32_t pass = static_cast<uint32_t>(p.lit_pass);  // records whose sample positions fit the LDS area at once
     uint32_t* s_lit = reinterpret_cast<uint32_t*>(s_pos + static_cast<size_t>(pass) * pairs_per_hit * 3);
     uint32_t* s_und = s_lit + round;  // the round's undecided records, packed
@@ -1167,6 +1168,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                     undecided = known < 0;
                     MCRT_HOOK_LIT_CLASSIFIED(known, undecided, cand, O)
                     s_cand[threadIdx.x] = cand;
+                    s_ins[threadIdx.x] = (undecided && p.inside_fast) ? origin_inside_boxes(sc, O, cand) : 0ull;
                     s_lit[threadIdx.x] = undecided ? 0u : static_cast<uint32_t>(known);
                 } else {
                     s_lit[threadIdx.x] = 0u;
@@ -1227,7 +1229,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
                         load_point_normal(ws, posed, base + k, P, N);
                         if (mode == SHADOW_HARD) N = normalize(N);
                         if (mode == SHADOW_SOFT)
-                            visible = !in_shadow_masked(sc, P, N, ld3(s_pos + static_cast<size_t>(q) * 3), s_cand[k]);
+                            visible = !in_shadow_masked(sc, P, N, ld3(s_pos + static_cast<size_t>(q) * 3), s_cand[k], s_ins[k]);
                         else
                             visible = !in_shadow_inline(sc, P, N, lpos);
                     }
@@ -1330,6 +1332,7 @@ __global__ __launch_bounds__(kBlock, MCRT_AO_WAVES) void ao_kernel(const uint8_t
             const V3 B = cross(N, T);
             const unsigned long long cand = s_mask[k];
             const V3 O = P + N * 1e-3f;
+            const unsigned long long inside = p.inside_fast ? origin_inside_boxes(sc, O, cand) : 0ull;  // every ray of the hit starts there
             MtShort rng;
             const uint32_t seed = ao_seed(P);
             if (p.seed_table_full)
@@ -1346,7 +1349,7 @@ __global__ __launch_bounds__(kBlock, MCRT_AO_WAVES) void ao_kernel(const uint8_t
                 mcrt_sincosf(kTwoPi * r2, &sn, &cs);
                 const V3 local = mk(sinT * cs, cosT, sinT * sn);
                 const V3 world = normalize(T * local.x + N * local.y + B * local.z);
-                if (any_hit_masked(sc, Ray{O, world}, radius, cand)) ++occluded;
+                if (any_hit_masked(sc, Ray{O, world}, radius, cand, inside)) ++occluded;
             }
             occ_out[e] = occluded;
         }
@@ -1771,7 +1774,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
         if (pass < 1) pass = 1;
         p.lit_round = kBlock;
         p.lit_pass = static_cast<int>(pass);
-        p.lit_lds_bytes = static_cast<int>(pass * 12 * pairs + static_cast<size_t>(kBlock) * 16);
+        p.lit_lds_bytes = static_cast<int>(pass * 12 * pairs + static_cast<size_t>(kBlock) * 24);  // positions + (candidates, inside, lit count, traced list) per record of a round
         p.lit_lds_offset = static_cast<int>((scene_table_bytes(p) + 15) & ~static_cast<size_t>(15));
     }
     const int owned = p.shard.owned_rows;

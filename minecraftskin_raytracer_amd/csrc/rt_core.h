@@ -755,14 +755,53 @@ DEV bool any_hit_inline(const SV& sc, const Ray& r, float limit) {
     }
     return false;
 }
+// mesh_candidate<true> for an UN-POSED mesh whose box holds the ray's origin STRICTLY inside (the caller has checked
+// lo < o < hi per axis): what intersectAABB does then, and nothing else.  Every non-parallel axis has t_near < 0 < t_far
+// (:229-236), so tmin < 0 and the reference takes the exit face — tmax with the axis of the smallest t_far, first axis on
+// ties (:255-288); the slab loop's reject (:246) cannot fire (tmin < 0 <= tmax); a transparent exit texel ends the test for
+// inner and outer layer alike (:312, :318: tmax > tHit fails when tHit IS tmax).  Most shadow and ambient-occlusion rays
+// that have candidates at all start under a transparent texel of their part's outer layer — inside that box — and this is
+// less than half the instructions of the general routine (no entry-face bookkeeping, no overlap logic, no second face).
+template <class SV>
+DEV bool mesh_candidate_inside(const SV& sc, const MeshData& m, int mesh_index, const RayQ& r, float t_limit) {
+    float t_exit = kFltMax;
+    int axis = 0;
+    bool neg = false;
+    auto far_side = [&](int i, bool par, float o, float inv, float l, float h) __attribute__((always_inline)) {
+        if (par) return;  // |d| < 1e-8: the origin is inside the slab, the axis takes no part (:222-227)
+        const float t0 = (l - o) * inv, t1 = (h - o) * inv;
+        const bool swapped = t0 > t1;
+        const float tf = swapped ? t0 : t1;
+        if (tf < t_exit) {  // == `tmax = min(tmax, t1)` and the exit-face scan's strict `<` (:241, :268-285)
+            t_exit = tf;
+            axis = i;
+            neg = swapped;
+        }
+    };
+    far_side(0, r.px, r.o.x, r.inv.x, m.lo.x, m.hi.x);
+    far_side(1, r.py, r.o.y, r.inv.y, m.lo.y, m.hi.y);
+    far_side(2, r.pz, r.o.z, r.inv.z, m.lo.z, m.hi.z);
+    if (!(t_exit < t_limit)) return false;  // local t is the reported t (un-posed)
+    if (m.flags & MESH_OPAQUE) return true;
+    const V3 hp = r.o + r.d * t_exit;
+    float u, v;
+    face_uv(hp, m.lo, m.hi, axis, neg, u, v);
+    return !(alpha_bits(sc, face_texel_index(sc, mesh_index, face_slot(axis, neg), u, v)) & 1u);  // texColor.a != 0 (:311)
+}
+
 // The same with the first pass already done for this ray (a per-hit conservative candidate mask):
 // only the exact second pass runs.  Scenes beyond 64 meshes still scan their tail exactly.
+// inside: the candidates whose (un-posed) box holds the ray's origin strictly inside (origin_inside_boxes)
 template <class SV>
-DEV bool any_hit_masked(const SV& sc, const Ray& r, float limit, unsigned long long cand) {
+DEV bool any_hit_masked(const SV& sc, const Ray& r, float limit, unsigned long long cand, unsigned long long inside = 0ull) {
     const RayQ q = prepare(r);
     while (cand) {
         const int i = __builtin_ctzll(cand);
         cand &= cand - 1ull;
+        if ((inside >> i) & 1ull) {
+            if (mesh_candidate_inside(sc, mesh_lane(sc, i), i, q, limit)) return true;
+            continue;
+        }
         Cand c;
         if (mesh_candidate<true>(sc, mesh_lane(sc, i), i, q, limit, c)) return true;
     }
@@ -1224,6 +1263,21 @@ DEV unsigned long long hemisphere_candidates(const SV& sc, V3 O, V3 N, float rad
     return cand;
 }
 
+// The candidates (bits < 64) whose box holds O strictly inside — un-posed, non-empty meshes only: for those
+// any_hit_masked takes mesh_candidate_inside.  Per lane, from the per-lane mesh table.
+template <class SV>
+DEV unsigned long long origin_inside_boxes(const SV& sc, V3 O, unsigned long long cand) {
+    unsigned long long inside = 0ull;
+    while (cand) {
+        const int j = __builtin_ctzll(cand);
+        cand &= cand - 1ull;
+        const MeshData m = mesh_lane(sc, j);
+        const bool plain = !(m.flags & MESH_EMPTY) && !(SV::kPosed && (m.flags & MESH_ROTATED));
+        if (plain & (O.x > m.lo.x) & (O.x < m.hi.x) & (O.y > m.lo.y) & (O.y < m.hi.y) & (O.z > m.lo.z) & (O.z < m.hi.z)) inside |= 1ull << j;
+    }
+    return inside;
+}
+
 // shared copy for the rare sequential paths (AO, very long shadow streams, probes)
 DEVCALL bool any_hit_call(SceneView sc, Ray r, float limit) { return any_hit_inline(sc, r, limit); }
 template <class SV>
@@ -1298,13 +1352,13 @@ DEV bool in_shadow_inline(const SV& sc, V3 point, V3 normal, V3 light) {
 
 // isInShadow for one of the S rays of a hit whose bundle mask is known
 template <class SV>
-DEV bool in_shadow_masked(const SV& sc, V3 point, V3 normal, V3 light, unsigned long long cand) {
+DEV bool in_shadow_masked(const SV& sc, V3 point, V3 normal, V3 light, unsigned long long cand, unsigned long long inside = 0ull) {
     V3 origin = point + normal * 1e-3f;
     V3 to = light - origin;
     float dist = length(to);
     if (dist < 1e-6f) return false;
     Ray r{origin, vdiv(to, dist)};
-    return any_hit_masked(sc, r, dist, cand);
+    return any_hit_masked(sc, r, dist, cand, inside);
 }
 
 // computeSoftShadow :28-60, sequential form (probes; `lit` spreads the samples over lanes)
