@@ -168,21 +168,36 @@ struct mcrt_scene {
 namespace {
 
 // workspace budget of a render (bytes, all lanes together); MCRT_WORKSPACE_MB overrides (tests use a
-// small value to force multi-batch renders).  By default a third of the CURRENT device's memory (96 GB of the
-// MI355X's 288), never more than 80 % of what is free right now: the workspace is sized for the worst case of every
+// small value to force multi-batch renders).  By default a third of the scene's device's memory (96 GB of the
+// MI355X's 288): the workspace is sized for the worst case of every
 // sample hitting (~300 B per sample), buffers only ever grow to what a frame needs, and a frame cut into few large
 // batches is much faster than many small ones (4K / 8 bounces / 16 spp: 9.7 ms with 4 GiB, 6.1 ms in one batch).
-size_t workspace_budget() {  // read per scene (current device = the scene's): tests switch it between renders
+// total memory of a device, asked once per device and process (hipMemGetInfo costs ~10 ms per call on this runtime: asked per
+// scene it made every one-shot render 12 ms longer)
+size_t device_total_memory(int device) {
+    static std::mutex mu;
+    static std::vector<size_t> totals;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0) return 0;
+    if (totals.size() <= static_cast<size_t>(device)) totals.resize(static_cast<size_t>(device) + 1, 0);
+    size_t& t = totals[static_cast<size_t>(device)];
+    if (t == 0) {
+        size_t total_b = 0;
+        if (hipDeviceTotalMem(&total_b, device) != hipSuccess) {
+            (void)hipGetLastError();
+            total_b = static_cast<size_t>(24) << 30;
+        }
+        t = total_b ? total_b : 1;
+    }
+    return t;
+}
+size_t workspace_budget(int device) {  // read per scene: tests switch MCRT_WORKSPACE_MB between renders
     const char* e = std::getenv("MCRT_WORKSPACE_MB");
     const long long mb = e ? std::atoll(e) : 0;
     if (mb > 0) return static_cast<size_t>(mb) << 20;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) {
-        (void)hipGetLastError();
-        return static_cast<size_t>(8) << 30;
-    }
-    const size_t third = total_b / 3, room = free_b / 5 * 4;
-    return std::max<size_t>(static_cast<size_t>(256) << 20, std::min(third, room));
+    // (when the device cannot give that much right now — other allocations, a shared GPU — prepare() halves the budget
+    // and re-plans instead of failing)
+    return std::max<size_t>(static_cast<size_t>(256) << 20, device_total_memory(device) / 3);
 }
 
 // lanes for a shard: enough work per lane that the extra launches pay (MCRT_LANES forces a count)
@@ -319,7 +334,7 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     else
         touched_tiles_per_row(sc, *cfg, p.shard, row_touched);
     for (;;) {
-        if (!sc->budget) sc->budget = workspace_budget();
+        if (!sc->budget) sc->budget = workspace_budget(sc->device);
         w = plan_workspace(p, sc->budget / static_cast<size_t>(n_lanes), row_touched.empty() ? nullptr : row_touched.data());
         if (p.rows_per_batch <= 0 && p.shard.owned_rows > 0)
             return fail(MCRT_ERR_INVALID, "one tile row holds more than 2^31 samples (width x tile size x samples per pixel)");
@@ -750,17 +765,7 @@ bool pool_scene(mcrt_scene* s) {
         const char* e = std::getenv("MCRT_POOL_MB");
         return e ? std::atoll(e) : -1ll;
     }();
-    size_t limit;
-    if (forced_mb >= 0) {
-        limit = static_cast<size_t>(forced_mb) << 20;
-    } else {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
-            (void)hipGetLastError();
-            total_b = 0;
-        }
-        limit = total_b / 12;
-    }
+    const size_t limit = forced_mb >= 0 ? static_cast<size_t>(forced_mb) << 20 : device_total_memory(s->device) / 12;
     if (workspace_bytes(s) > limit) return false;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (mcrt_scene* q : g_pool)

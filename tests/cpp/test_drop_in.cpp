@@ -136,6 +136,25 @@ int main(int argc, char** argv) {
                 else restUntouched = restUntouched && p == Color();
             }
         CHECK(tileSame && restUntouched && TileRenderer::lastErrors().empty());
+        // renderTile takes ANY Tile of the frame (tile_renderer.cpp:71-127), on or off the tile grid: twice the same pixels,
+        // nothing outside the rectangle, no error; a rectangle that leaves the frame is refused (the reference would write
+        // out of bounds)
+        const Tile odd{5, 3, 17, 9};
+        Image a1(c.width, c.height), a2(c.width, c.height);
+        TileRenderer::renderTile(odd, scene, c, a1);
+        TileRenderer::renderTile(odd, scene, c, a2);
+        bool same2 = true, outside = true, touched = false;
+        for (int y = 0; y < c.height; ++y)
+            for (int x = 0; x < c.width; ++x) {
+                const bool in = x >= odd.x && x < odd.x + odd.width && y >= odd.y && y < odd.y + odd.height;
+                const Color& p1 = a1.pixels[y * c.width + x];
+                same2 = same2 && p1 == a2.pixels[y * c.width + x];
+                if (in) touched = touched || !(p1 == Color());
+                else outside = outside && p1 == Color();
+            }
+        CHECK(same2 && outside && touched && TileRenderer::lastErrors().empty());
+        TileRenderer::renderTile(Tile{30, 20, 8, 8}, scene, c, a1);
+        CHECK(!TileRenderer::lastErrors().empty());
     }
     // ImageWriter::writePNG — test_image_writer.cpp: empty image and bad path → false; a valid image
     // → a PNG file that starts with the PNG signature and carries the IHDR dimensions
