@@ -388,7 +388,7 @@ def main() -> None:
         reused, _ = timed(n_calls, out=host)
         untouched = []
         import mmap
-        for _ in range(5):  # a destination whose pages were never touched (a fresh anonymous mapping): the library takes its pinned ring
+        for _ in range(5):  # a destination whose pages were never touched (a fresh anonymous mapping): the runtime's pinning faults them in
             mm = mmap.mmap(-1, h * w * 16)
             fresh = np.frombuffer(mm, np.float32).reshape(h, w, 4)
             t0 = time.perf_counter()
@@ -408,7 +408,7 @@ def main() -> None:
             "what": "median wall time of TileRenderer.render (mcrt_render behind it) returning a FRESH Image per call, as the reference's call "
                     "site gets one: Image(W,H) allocation and (0,0,0,1) fill + scene flatten + upload + kernels + row-group downloads "
                     "overlapping the render + progress bookkeeping; reused_buffer_ms = the same call into one caller-owned buffer; "
-                    "untouched_buffer_ms = into never-touched pages (a fresh anonymous mapping: rows go through the pinned ring and copy threads); split_ms = the "
+                    "untouched_buffer_ms = into never-touched pages (a fresh anonymous mapping, what a bare malloc behind the C ABI is); split_ms = the "
                     "library's own split of the C call (mcrt_last_timings)",
         }
         if not args.quick_host:

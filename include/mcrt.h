@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define MCRT_ABI_VERSION 3 /* 2: mcrt_render_multi, MCRT_DEVICE_ALL; mcrt_time_render_device lost its second output
-                            * 3: mcrt_render_rgba8, mcrt_render_rect, mcrt_parallel_copy */
+                            * 3: mcrt_render_rgba8, mcrt_render_rect */
 
 /* error codes (0 = ok) */
 #define MCRT_OK 0
@@ -238,12 +238,6 @@ int mcrt_assemble_frame_device(const mcrt_config* cfg, int world, const float* d
  * (/root/reference/src/output/image_writer.cpp:18-22 ≡ src/skin/image.cpp:31-36). */
 int mcrt_quantize_rgba8_device(const float* d_rgba, uint8_t* d_out, size_t n_pixels, void* stream);
 void mcrt_quantize_rgba8(const float* rgba, uint8_t* out, size_t n_pixels);
-/* Host utility of the host-buffer paths: dst[0 .. bytes) = src[0 .. bytes), split over the library's copy threads
- * (MCRT_COPY_THREADS, default 8) and the calling thread.  mcrt_render lands the frame's rows in a pinned ring and
- * copies each landed piece into the caller's frame with it — a frame buffer the HIP runtime has never seen (the
- * reference's call site gets a fresh Image per call) would otherwise be pinned page by page first.  May be called
- * from several threads. */
-void mcrt_parallel_copy(void* dst, const void* src, size_t bytes);
 
 /* ---- PNG hand-off (the step after the path: ImageWriter::writePNG, image_writer.cpp:6-28) -------- */
 /* Writes an 8-bit RGBA PNG (colour type 6, no interlace, filter 0, zlib *stored* blocks: no

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "mcrt_probe_mt_uniform", "mcrt_probe_detmath", "mcrt_probe_detmath_range", "mcrt_probe_div_const",
     "mcrt_render_device_ex", "mcrt_write_png_rgba8", "mcrt_encode_png_rgba8", "mcrt_write_png_f32", "mcrt_render_png",
     "mcrt_assemble_frame_device", "mcrt_scene_set_lanes", "mcrt_trim", "mcrt_scene_check", "mcrt_render_multi",
-    "mcrt_parallel_copy", "mcrt_render_rgba8", "mcrt_render_rect",
+    "mcrt_render_rgba8", "mcrt_render_rect",
 ]
 
 
@@ -68,7 +68,6 @@ def load():
         "mcrt_unpack_rows_device": (C.c_int, [cfg_p, C.c_int, C.c_int, vp, vp, vp]),
         "mcrt_quantize_rgba8_device": (C.c_int, [vp, vp, C.c_size_t, vp]),
         "mcrt_quantize_rgba8": (None, [f_p, u8_p, C.c_size_t]),
-        "mcrt_parallel_copy": (None, [vp, vp, C.c_size_t]),
         "mcrt_last_timings": (C.c_int, [C.POINTER(abi.McrtTimings)]),
         "mcrt_time_render_device": (C.c_int, [vp, cfg_p, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, f_p]),
         "mcrt_render_multi": (C.c_int, [desc_p, cfg_p, f_p, abi.PROGRESS_FN, vp, C.POINTER(C.c_int), C.c_int, C.c_int]),

@@ -17,8 +17,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libmcrt.so")
-SOURCES = ["render_kernels.hip", "api.cpp", "flatten.cpp", "scene_builder.cpp", "png_writer.cpp", "copy_pool.cpp"]
-HEADERS = ["flat_scene.h", "flatten.h", "kernels.h", "rt_core.h", "copy_pool.h"]
+SOURCES = ["render_kernels.hip", "api.cpp", "flatten.cpp", "scene_builder.cpp", "png_writer.cpp"]
+HEADERS = ["flat_scene.h", "flatten.h", "kernels.h", "rt_core.h"]
 ARCH = "gfx950"
 
 

@@ -2,7 +2,6 @@
 //
 // There is deliberately no CPU fallback anywhere in this file: every render / probe entry point
 // needs a HIP device and fails with MCRT_ERR_NO_DEVICE / MCRT_ERR_HIP otherwise.
-#include "copy_pool.h"
 #include "flatten.h"
 #include "kernels.h"
 #include "mcrt.h"
@@ -10,8 +9,6 @@
 
 #include <hip/hip_runtime.h>
 
-#include <sys/mman.h>
-#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -155,10 +152,6 @@ struct mcrt_scene {
     // back): no pin / unpin of a few KB of pageable memory per call
     void* staging = nullptr;
     size_t staging_bytes = 0;
-    // pinned ring the rows of a host-buffer render land in before worker threads copy them into the caller's frame
-    // (kRingSlots pieces of kRingPiece bytes; see download_staged)
-    void* ring = nullptr;
-    hipEvent_t ring_ev[16] = {};
     const uint32_t* seed_table = nullptr;  // the device's table of mt19937 seeding results (kernels.h), or NULL
     bool holds_seed_table = false;
     const uint32_t* seed_table_full = nullptr;  // the device's table for every 32-bit seed (ambient occlusion), or NULL
@@ -954,9 +947,6 @@ void destroy_scene_now(mcrt_scene* s) {
     if (s->fork) (void)hipEventDestroy(s->fork);
     if (s->last_done) (void)hipEventDestroy(s->last_done);
     if (s->staging) (void)hipHostFree(s->staging);
-    if (s->ring) (void)hipHostFree(s->ring);
-    for (hipEvent_t ev : s->ring_ev)
-        if (ev) (void)hipEventDestroy(ev);
     if (s->main_stream) (void)hipStreamDestroy(s->main_stream);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     for (hipEvent_t m : s->marks) (void)hipEventDestroy(m);
@@ -1077,79 +1067,11 @@ int validate_config(const mcrt_config* cfg) {
     return MCRT_OK;
 }
 
-// ---- host-buffer downloads through a pinned ring ---------------------------------------------------------
-// hipMemcpyAsync into pageable memory the runtime has not seen before pins the pages first: ~2.6 ms per 33 MB
-// (tools/micro/d2h.cpp) — and the reference's call site gets a fresh Image per call (tile_renderer.cpp:141).  So the
-// rows land in a pinned ring owned by the (pooled) scene shell at PCIe rate, piece by piece, and a few worker threads
-// copy each landed piece into the caller's frame while the next pieces are still on the bus.
-constexpr size_t kRingPiece = static_cast<size_t>(4) << 20;
-constexpr int kRingSlots = 16;
-
 struct CopySpan {  // a contiguous run: device bytes → host bytes
     const char* src;
     char* dst;
     size_t bytes;
 };
-// How the rows reach the caller's frame.  Measured on the MI355X box (profiles/r03_*): into pages that are RESIDENT — an
-// Image the caller has just value-initialised, as the reference's call site does (tile_renderer.cpp:141), or a buffer it
-// reuses — hipMemcpyAsync straight into them is fastest (0.65 ms for the 33 MB frame; the ring costs 0.3 ms more); into
-// pages that were never touched (a fresh malloc / np.empty) the runtime's pinning faults them in one by one (~2.6 ms),
-// and the ring with its copy threads wins.  MCRT_HOST_COPY = direct | staged forces one; the default asks the kernel
-// (mincore) whether the destination is resident.
-bool host_copy_staged(const void* dst, size_t bytes) {
-    static const int forced = [] {
-        const char* e = std::getenv("MCRT_HOST_COPY");
-        if (e && std::strcmp(e, "direct") == 0) return 0;
-        if (e && std::strcmp(e, "staged") == 0) return 1;
-        return -1;
-    }();
-    if (forced >= 0) return forced != 0;
-    const long page = sysconf(_SC_PAGESIZE);
-    if (page <= 0 || bytes < static_cast<size_t>(page) * 64) return false;
-    const uintptr_t a = reinterpret_cast<uintptr_t>(dst) & ~static_cast<uintptr_t>(page - 1);
-    const size_t span = reinterpret_cast<uintptr_t>(dst) + bytes - a;
-    const size_t pages = (span + static_cast<size_t>(page) - 1) / static_cast<size_t>(page);
-    std::vector<unsigned char> vec(pages);
-    if (mincore(reinterpret_cast<void*>(a), span, vec.data()) != 0) return false;
-    size_t resident = 0;
-    for (unsigned char v : vec) resident += v & 1u;
-    return resident * 2 < pages;  // mostly untouched: let the copy threads fault the pages in
-}
-hipError_t ensure_ring(mcrt_scene* s) {
-    if (s->ring) return hipSuccess;
-    hipError_t e = hipHostMalloc(&s->ring, kRingPiece * kRingSlots, hipHostMallocDefault);
-    for (int i = 0; i < kRingSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->ring_ev[i], hipEventDisableTiming);
-    return e;
-}
-// the spans through the scene's ring on its copy stream; `parallel`: landed pieces are copied out by the pool (one rank),
-// else by the calling thread alone (one copier thread per rank already)
-hipError_t download_staged(mcrt_scene* s, const std::vector<CopySpan>& spans, bool parallel) {
-    hipError_t e = ensure_ring(s);
-    if (e != hipSuccess) return e;
-    std::vector<CopySpan> pieces;
-    for (const CopySpan& sp : spans)
-        for (size_t off = 0; off < sp.bytes; off += kRingPiece) pieces.push_back(CopySpan{sp.src + off, sp.dst + off, std::min(kRingPiece, sp.bytes - off)});
-    size_t issued = 0;
-    char* ring = static_cast<char*>(s->ring);
-    for (size_t k = 0; k < pieces.size() && e == hipSuccess; ++k) {
-        while (issued < pieces.size() && issued < k + static_cast<size_t>(kRingSlots) && e == hipSuccess) {  // keep the bus busy: up to a ring of pieces ahead
-            const int slot = static_cast<int>(issued % kRingSlots);
-            e = hipMemcpyAsync(ring + static_cast<size_t>(slot) * kRingPiece, pieces[issued].src, pieces[issued].bytes, hipMemcpyDeviceToHost, s->copy_stream);
-            if (e == hipSuccess) e = hipEventRecord(s->ring_ev[slot], s->copy_stream);
-            ++issued;
-        }
-        if (e != hipSuccess) break;
-        const int slot = static_cast<int>(k % kRingSlots);
-        e = hipEventSynchronize(s->ring_ev[slot]);
-        if (e != hipSuccess) break;
-        if (parallel)
-            parallel_copy(pieces[k].dst, ring + static_cast<size_t>(slot) * kRingPiece, pieces[k].bytes);
-        else
-            std::memcpy(pieces[k].dst, ring + static_cast<size_t>(slot) * kRingPiece, pieces[k].bytes);
-    }
-    if (e != hipSuccess) (void)hipStreamSynchronize(s->copy_stream);  // nothing of this call stays in flight
-    return e;
-}
 
 int one_shot_streams(mcrt_scene* s) {
     if (!s->main_stream) HIP_TRY(hipStreamCreateWithFlags(&s->main_stream, hipStreamNonBlocking));
@@ -1283,10 +1205,11 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, void* ou
         }
         return spans;
     };
-    // the spans on `s`'s copy stream: straight into the caller's pages, or through the pinned ring (host_copy_staged)
-    const bool staged = host_copy_staged(out, whole_bytes);
-    auto download = [&](mcrt_scene* s, const std::vector<CopySpan>& spans, bool pool) -> hipError_t {
-        if (staged) return download_staged(s, spans, pool);
+    // the spans on `s`'s copy stream, straight into the caller's pages.  (Measured and rejected, profiles/r03_experiments:
+    // landing the rows in a pinned ring and copying them out with several threads — 1.08 ms instead of 0.77 for resident
+    // pages, 9.8 ms instead of 4.0 for pages that were never touched: eight threads faulting pages of one address space
+    // serialise on its lock, while the runtime's own pinning faults them in bulk.)
+    auto download = [&](mcrt_scene* s, const std::vector<CopySpan>& spans) -> hipError_t {
         hipError_t ce = hipSuccess;
         for (const CopySpan& sp : spans)
             if (ce == hipSuccess) ce = hipMemcpyAsync(sp.dst, sp.src, sp.bytes, hipMemcpyDeviceToHost, s->copy_stream);
@@ -1304,7 +1227,7 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, void* ou
             const RowGroup& grp = hr.groups[g];
             for (size_t i = 0; i < grp.wait.size() && ce == hipSuccess; ++i) ce = hipEventSynchronize(grp.wait[i]);
             if (ce != hipSuccess) return ce;
-            return download(s, spans_of(static_cast<const char*>(s->frame.ptr), grp.rows, n_ranks == 1 ? -1 : r), n_ranks == 1);
+            return download(s, spans_of(static_cast<const char*>(s->frame.ptr), grp.rows, n_ranks == 1 ? -1 : r));
         };
         if (n_ranks == 1) {
             for (size_t g = 0; g < ranks[0].groups.size() && e == hipSuccess; ++g) {
@@ -1386,7 +1309,7 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, void* ou
             e = hipEventSynchronize(unpacked[static_cast<size_t>(r)]);
             std::vector<int> rows;
             for (int row = r; row < all.tiles_y; row += n_ranks) rows.push_back(row);
-            if (e == hipSuccess) e = download(root, spans_of(assembled, rows, -1), true);
+            if (e == hipSuccess) e = download(root, spans_of(assembled, rows, -1));
             if (e == hipSuccess) report_rows(rows);
         }
     }
@@ -1515,10 +1438,6 @@ int mcrt_render_png(const mcrt_scene_desc* desc, const mcrt_config* cfg, const c
                                              : mcrt_render_rgba8(desc, cfg, host.data(), nullptr, nullptr, &device, 1, 0);
     if (rc != MCRT_OK) return rc;
     return mcrt_write_png_rgba8(path, host.data(), cfg->width, cfg->height);
-}
-
-void mcrt_parallel_copy(void* dst, const void* src, size_t bytes) {
-    if (dst && src && bytes) parallel_copy(dst, src, bytes);
 }
 
 int mcrt_last_timings(mcrt_timings* out) {

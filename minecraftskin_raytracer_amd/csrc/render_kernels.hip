@@ -255,9 +255,12 @@ __device__ __forceinline__ void fill_tile(const RenderParams& p, const TileGeom&
 
 // executed by one wave; `st` = its 2 x 624 words of LDS.  dst != nullptr: the tile's draws go there;
 // dst == nullptr: a background tile, rendered from the draws in LDS.
+// jitter_only (a background tile under depth of field, 4 draws per sample): only the samples' jitter pairs are stored,
+// packed — sample k's at dst[2k], dst[2k + 1]; no ray leaves a background tile, so its lens draws are never read
+// (tile_renderer.cpp:99-114), and they are half of the stream `primary` would read back.
 __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint32_t* __restrict__ tile_rng, float* __restrict__ dst,
                                                  float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams& p,
-                                                 const TileGeom& tg, int tile, uint32_t* st, int lane) {
+                                                 const TileGeom& tg, int tile, uint32_t* st, int lane, bool jitter_only = false) {
     const int spp = p.cfg.samples_per_pixel > 1 ? p.cfg.samples_per_pixel : 1;
     const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
     const unsigned per_pixel = static_cast<unsigned>(spp) * static_cast<unsigned>(p.draws_per_sample);
@@ -297,7 +300,14 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
         cur ^= 1;
         const unsigned left = total - done;
         const int m = left < 624u ? static_cast<int>(left) : 624;
-        if (dst) {
+        if (dst && jitter_only) {  // wave-uniform; done is a multiple of 624 = 4 x 156: draw done + e is a jitter draw iff (e & 2) == 0
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int k = lane + 64 * i;  // the k-th jitter draw of this twist
+                const int e = ((k >> 1) << 2) | (k & 1);
+                if (e < m) dst[(done >> 1) + static_cast<unsigned>(k)] = mt_to_unit(mt_temper(n[e]));
+            }
+        } else if (dst) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
                 const int e = lane + 64 * i;
@@ -592,7 +602,9 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
     const size_t stride = p.ws.draws_stride;
     if (!p.bg_in_plan) {  // every tile's draws to HBM; `primary` renders the background tiles (those of one colour need no draws)
         float4 unused;
-        if (p.draws_per_sample > 0 && !(plan.mask == 0ull && constant_background(sc, p, tg, unused))) tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(t) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
+        if (p.draws_per_sample > 0 && !(plan.mask == 0ull && constant_background(sc, p, tg, unused)))
+            tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(t) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane,
+                             /*jitter_only=*/plan.mask == 0ull && p.draws_per_sample == 4);
     } else if (plan.mask != 0ull) {  // a tile meshes can touch: its draws, at its touched-tile number
         if (p.draws_per_sample > 0 && plan.ord != ~0u)
             tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(plan.ord) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
@@ -766,13 +778,15 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
             const int ly = static_cast<int>(uly);
             const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
             const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
-            const float* jd = draws + static_cast<size_t>(pix) * spp * dd;
+            // (under depth of field a background tile's stream holds the jitter pairs only, packed: tile_stream_wave)
+            const int jd_step = dd == 4 ? 2 : dd;
+            const float* jd = draws + static_cast<size_t>(pix) * spp * jd_step;
             float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
             for (int sidx = 0; sidx < spp; ++sidx) {
                 float jx = 0.5f, jy = 0.5f;
                 if (spp > 1) {
-                    jx = jd[sidx * dd];
-                    jy = jd[sidx * dd + 1];
+                    jx = jd[sidx * jd_step];
+                    jy = jd[sidx * jd_step + 1];
                 }
                 const C4 c = background(sc, cfg, fd.u(fx + jx), fd.v(fy + jy));  // tile_renderer.cpp:111-114
                 ar += c.r;

@@ -1,7 +1,6 @@
 // ASan/UBSan driver for the pure-host parts: scene builder + flattener over every pose and skin layout,
 // plus malformed descriptions.
 #include "flatten.h"
-#include "copy_pool.h"
 #include "mcrt.h"
 #include <cmath>
 #include <cstdlib>
@@ -9,8 +8,6 @@
 #include <cstdio>
 #include <cstdint>
 #include <string>
-#include <atomic>
-#include <thread>
 #include <vector>
 int mcrt_detail_fail(int code, const char*) { return code; }  // api.cpp's error hook (not linked here)
 
@@ -41,33 +38,8 @@ static int png_checks() {
     return bad;
 }
 
-// the copy pool behind mcrt_render's host downloads: odd sizes, overlapping callers
-static int copy_checks() {
-    int bad = 0;
-    const size_t sizes[] = {1, 63, 4096, (1u << 20) + 17, (9u << 20) + 5};
-    for (size_t n : sizes) {
-        std::vector<uint8_t> a(n), b(n, 0);
-        for (size_t i = 0; i < n; ++i) a[i] = static_cast<uint8_t>(i * 2654435761u >> 13);
-        mcrt::parallel_copy(b.data(), a.data(), n);
-        if (a != b) ++bad;
-    }
-    std::vector<std::thread> callers;
-    std::atomic<int> wrong{0};
-    for (int t = 0; t < 4; ++t)
-        callers.emplace_back([t, &wrong] {
-            for (int rep = 0; rep < 6; ++rep) {
-                const size_t n = (3u << 20) + static_cast<size_t>(t) * 1237 + static_cast<size_t>(rep);
-                std::vector<uint8_t> a(n, static_cast<uint8_t>(t * 16 + rep)), b(n, 0xee);
-                mcrt::parallel_copy(b.data(), a.data(), n);
-                if (a != b) ++wrong;
-            }
-        });
-    for (auto& c : callers) c.join();
-    return bad + wrong.load();
-}
-
 int main() {
-    int bad = png_checks() + copy_checks();
+    int bad = png_checks();
     for (int legacy = 0; legacy < 2; ++legacy) {
         const int w = 64, h = legacy ? 32 : 64;
         std::vector<uint8_t> skin(static_cast<size_t>(w) * h * 4);

@@ -255,30 +255,3 @@ def test_gather_progress_follows_the_ranks_as_they_land(mcrt, oracle, gpu, ranks
     for done, snap in snaps:
         assert tiles_final(snap, ref, cfg) >= done
     assert tiles_final(snaps[0][1], ref, cfg) < total  # the first report came before the last rank had landed
-
-
-def test_direct_and_staged_downloads_agree(mcrt, gpu, tmp_path):
-    """MCRT_HOST_COPY=direct (hipMemcpyAsync straight into the caller's pages), =staged (pinned ring + copy threads) and
-    the default (by the residency of the destination's pages) deliver the same frame.  (Read once per process → subprocess.)"""
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "render.py"
-    script.write_text(
-        "import sys, numpy as np\n"
-        f"sys.path.insert(0, {repr(root)}); sys.path.insert(0, {repr(os.path.join(root, 'tests'))})\n"
-        "import minecraftskin_raytracer_amd as M, scenes\n"
-        "sd = scenes.skin_scene('S64', 6)\n"
-        "a = np.empty((1080, 1920, 4), np.float32)\n"  # untouched pages: the default takes the ring here
-        "M.TileRenderer.render(sd, M.Config(width=1920, height=1080, maxBounces=2, samplesPerPixel=2), out=a)\n"
-        "b = M.TileRenderer.render(sd, M.Config(width=200, height=150, maxBounces=2, samplesPerPixel=2), device=[0, 0])\n"
-        "assert M.TileRenderer.lastErrors() == []\n"
-        "np.save(sys.argv[1], a); np.save(sys.argv[2], b)\n")
-    names = [str(tmp_path / n) for n in ("a0.npy", "b0.npy", "a1.npy", "b1.npy", "a2.npy", "b2.npy")]
-    subprocess.check_call([sys.executable, str(script), names[0], names[1]])
-    subprocess.check_call([sys.executable, str(script), names[2], names[3]], env=dict(os.environ, MCRT_HOST_COPY="direct"))
-    subprocess.check_call([sys.executable, str(script), names[4], names[5]], env=dict(os.environ, MCRT_HOST_COPY="staged"))
-    for k in (2, 4):
-        assert np.array_equal(np.load(names[0]).view(np.uint32), np.load(names[k]).view(np.uint32))
-        assert np.array_equal(np.load(names[1]).view(np.uint32), np.load(names[k + 1]).view(np.uint32))

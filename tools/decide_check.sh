@@ -8,7 +8,7 @@ C=$R/minecraftskin_raytracer_amd/csrc
 if [ "$1" = build ]; then
   mkdir -p $R/variants
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I$R/include -I$C -I$R/tools '-DMCRT_KERNEL_HOOKS="decide_check_hooks.h"' \
-    $C/render_kernels.hip $C/api.cpp $C/flatten.cpp $C/scene_builder.cpp $C/png_writer.cpp $C/copy_pool.cpp -o $R/variants/decide_check.so -lpthread
+    $C/render_kernels.hip $C/api.cpp $C/flatten.cpp $C/scene_builder.cpp $C/png_writer.cpp -o $R/variants/decide_check.so -lpthread
   exit $?
 fi
 first=${2:-900000}; count=${3:-2000}
