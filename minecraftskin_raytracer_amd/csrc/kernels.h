@@ -103,6 +103,8 @@ struct RenderParams {
     int rows_per_batch;    // owned tile rows per pipeline pass
     int bg_in_plan;        // 1: `plan_tiles` renders the background tiles from the draws in LDS and only touched tiles' draws
                            //    go to HBM; 0 (more than 24 draws per pixel): all streams to HBM, `primary` renders them
+    int bg_kernel;         // 1 (bg_in_plan == 0 and many samples per pixel): `background_kernel` renders the background tiles from their
+                           //    streams, slab by slab through LDS; 0: `primary`'s tail does, a lane per pixel straight from HBM
     int lit_round;         // `lit`: records per round (a block of 256)
     int lit_pass;          // `lit`: traced records per pass (their light samples live in LDS between two phases)
     int lit_lds_offset;    // `lit`: byte offset of that area in dynamic LDS (behind the scene tables, 16-aligned)

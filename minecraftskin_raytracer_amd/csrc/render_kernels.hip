@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
     const mcrt_config& cfg = p.cfg;
     const WaveSpace& ws = p.ws;
     const uint32_t n_units = ws.counters[kCntUnits];
-    if (p.bg_in_plan && blockIdx.x >= n_units) return;  // nothing for this workgroup: leave before the collective staging
+    if ((p.bg_in_plan || p.bg_kernel) && blockIdx.x >= n_units) return;  // nothing for this workgroup: leave before the collective staging
     // flat pipeline: the reflection ray of every primary hit (raytracer.cpp:133-139) is traced right here, by the first
     // `total` threads of the block on the chunk's packed hits (as a launch of its own this stage re-read every record:
     // 39 + 28 us became 59 us)
@@ -656,7 +656,6 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
     const FrameDiv fd(p);
     float focusDist = cfg.focus_distance;
     if (focusDist <= 0.0f) focusDist = sc.hdr->cam_focus_auto;
-    const float inv_spp = 1.0f / static_cast<float>(spp);
     const size_t stride = ws.draws_stride;
 
     // ================= units of tiles that meshes can touch: thread per sample =================
@@ -759,10 +758,13 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
         if (tid == 0) ws.unit_hits[u] = unit_hits;
     }
 
+
     // ================= background tiles: nothing can be hit, no ray is needed =================
-    // (only when a pixel's draws exceed one twist — otherwise `plan_tiles` has rendered them from LDS)
+    // (only when a pixel takes more than 24 draws — otherwise `plan_tiles` has rendered them from LDS — and at most
+    // kSlabMinSpp - 1 samples: above that `background_kernel` does it)
     // thread per pixel, its samples in order as renderTile sums them (tile_renderer.cpp:116-124); no barriers
-    if (p.bg_in_plan) return;
+    if (p.bg_in_plan || p.bg_kernel) return;
+    const float inv_spp = 1.0f / static_cast<float>(spp);
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int tile = tile_base + t;
         if (ws.tile_mask[tile] != 0ull) continue;  // uniform
@@ -772,23 +774,18 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
             continue;
         }
         const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
-        const float* draws = tile_draws + static_cast<size_t>(t) * stride;
+        // the tile's jitter pairs, pixel-major (under depth of field a background tile's stream holds them only, packed: tile_stream_wave)
+        const float2* pairs = reinterpret_cast<const float2*>(tile_draws + static_cast<size_t>(t) * stride);
         for (unsigned pix = tid; pix < npix; pix += kBlock) {
             const unsigned uly = pix / static_cast<unsigned>(tg.w);
             const int ly = static_cast<int>(uly);
             const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
             const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
-            // (under depth of field a background tile's stream holds the jitter pairs only, packed: tile_stream_wave)
-            const int jd_step = dd == 4 ? 2 : dd;
-            const float* jd = draws + static_cast<size_t>(pix) * spp * jd_step;
+            const float2* jd = pairs + static_cast<size_t>(pix) * spp;
             float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
             for (int sidx = 0; sidx < spp; ++sidx) {
-                float jx = 0.5f, jy = 0.5f;
-                if (spp > 1) {
-                    jx = jd[sidx * jd_step];
-                    jy = jd[sidx * jd_step + 1];
-                }
-                const C4 c = background(sc, cfg, fd.u(fx + jx), fd.v(fy + jy));  // tile_renderer.cpp:111-114
+                const float2 j = jd[sidx];
+                const C4 c = background(sc, cfg, fd.u(fx + j.x), fd.v(fy + j.y));  // tile_renderer.cpp:111-114
                 ar += c.r;
                 ag += c.g;
                 ab += c.b;
@@ -797,6 +794,86 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
             const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
             store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx),
                         make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// background: the tiles no mesh can touch at HIGH sample counts (kSlabMinSpp samples per pixel and more; below that the
+// loop above, in `primary`'s tail, does as well).  The tile's stream in HBM is pixel-major — a pixel's spp jitter pairs
+// side by side, 8·spp bytes per pixel — so a lane per pixel reads it at a stride of 8·spp bytes: at 64 spp that is 64 cache
+// lines per load instruction and 32 KB of lines per wave in flight, more than the L1 holds: the loop was bound by those
+// transactions (8.4 of the 8K / 64 spp frame's 14.3 ms per pass).  Here a wave fetches a SLAB — 64 pixels x 16 samples — with
+// neighbouring lanes on neighbouring pairs (every line touched once and used whole), parks it in LDS with the pixels' rows
+// padded by one pair (a lane per pixel then reads at a stride of 34 words: two lanes per bank) and consumes it, a lane per
+// pixel, samples in order (tile_renderer.cpp:116-124); waves work on their own: no workgroup barrier.  8K / 64 spp: 20.4 ->
+// 17.1 ms alone; at 16 spp the staging costs 3-5 % more than it saves (same-box A/B, profiles/r03_experiments).
+// ---------------------------------------------------------------------------------------------
+constexpr int kSlabSamples = 16;
+constexpr int kSlabMinSpp = 33;  // `background_kernel` from this many samples per pixel on
+__global__ __launch_bounds__(kBlock) void background_kernel(const uint8_t* __restrict__ scene_blob, const float* __restrict__ tile_draws,
+                                                            float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p,
+                                                            const int tile_base, const int n_tiles) {
+    __shared__ __align__(16) float2 s_slab[kBlock / 64][64][kSlabSamples + 1];
+    const SceneView sc = view_of(scene_blob);
+    const mcrt_config& cfg = p.cfg;
+    const WaveSpace& ws = p.ws;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned spp = static_cast<unsigned>(cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1);
+    const FrameDiv fd(p);
+    const float inv_spp = 1.0f / static_cast<float>(spp);
+    const size_t stride = ws.draws_stride;
+    float2(*slab)[kSlabSamples + 1] = s_slab[wave];
+    auto wave_sync = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tile = tile_base + t;
+        if (ws.tile_mask[tile] != 0ull) continue;  // uniform
+        const TileGeom tg = tile_of(p, tile);
+        if (float4 pixel; constant_background(sc, p, tg, pixel)) {  // uniform
+            fill_tile(p, tg, out_frame, out8, pixel, threadIdx.x, static_cast<unsigned>(kBlock));
+            continue;
+        }
+        const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
+        // the tile's jitter pairs, pixel-major: pair s of pixel q at pairs[q * spp + s] (under depth of field the stream of a
+        // background tile holds the jitter pairs only, packed: tile_stream_wave)
+        const float2* pairs = reinterpret_cast<const float2*>(tile_draws + static_cast<size_t>(t) * stride);
+        const UDiv by_w(static_cast<unsigned>(tg.w));
+        for (unsigned g0 = static_cast<unsigned>(wave) * 64u; g0 < npix; g0 += kBlock) {  // this wave's groups of 64 pixels
+            const unsigned group = min(64u, npix - g0);
+            const unsigned pix = g0 + static_cast<unsigned>(lane);
+            const unsigned uly = by_w.div(pix);
+            const int ly = static_cast<int>(uly);
+            const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
+            const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
+            float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
+            for (unsigned s0 = 0; s0 < spp; s0 += kSlabSamples) {  // uniform
+                const unsigned ns = min(static_cast<unsigned>(kSlabSamples), spp - s0);
+                const UDiv by_ns(ns);
+                const unsigned items = group * ns;
+                for (unsigned c = static_cast<unsigned>(lane); c < items; c += 64u) {  // neighbouring lanes, neighbouring pairs
+                    const unsigned q = by_ns.div(c), k = c - q * ns;
+                    slab[q][k] = pairs[static_cast<size_t>(g0 + q) * spp + s0 + k];
+                }
+                wave_sync();
+                if (static_cast<unsigned>(lane) < group) {
+                    for (unsigned k = 0; k < ns; ++k) {
+                        const float2 j = slab[lane][k];
+                        const C4 col = background(sc, cfg, fd.u(fx + j.x), fd.v(fy + j.y));  // tile_renderer.cpp:111-114
+                        ar += col.r;
+                        ag += col.g;
+                        ab += col.b;
+                        aa += col.a;
+                    }
+                }
+                wave_sync();  // the next slab overwrites this one
+            }
+            if (static_cast<unsigned>(lane) < group) {
+                const int row = (p.layout == MCRT_LAYOUT_PACKED) ? ((p.shard.pack_first + tg.owned_row * p.shard.pack_step) * cfg.tile_size + ly) : (tg.y + ly);
+                store_pixel(out_frame, out8, static_cast<size_t>(row) * cfg.width + (tg.x + lx), make_float4(ar * inv_spp, ag * inv_spp, ab * inv_spp, aa * inv_spp));
+            }
         }
     }
 }
@@ -1808,6 +1885,12 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     // the wave's 64 lanes), of every tile of the batch otherwise
     const size_t draws_stride = tile_slots * static_cast<size_t>(p.draws_per_sample);
     p.bg_in_plan = spp * static_cast<size_t>(p.draws_per_sample) <= 24 ? 1 : 0;
+    static const size_t slab_min_spp = [] {  // development knob (the parity sweeps run the slab kernel at every sample count with it)
+        const char* e = getenv("MCRT_SLAB_MIN_SPP");
+        const int v = e ? atoi(e) : 0;
+        return static_cast<size_t>(v > 0 ? v : kSlabMinSpp);
+    }();
+    p.bg_kernel = (!p.bg_in_plan && spp >= slab_min_spp) ? 1 : 0;
     const size_t draws_row_bytes = p.bg_in_plan ? 0 : draws_stride * 4 * static_cast<size_t>(p.shard.tiles_x);
     const size_t draws_tile_bytes = p.bg_in_plan ? draws_stride * 4 : 0;
     p.ws.draws_stride = static_cast<uint32_t>(draws_stride > 0xffffffffull ? 0xffffffffull : draws_stride);
@@ -1920,6 +2003,8 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
             e = hipEventRecord(marks->after_plan, stream);
             if (e != hipSuccess) return e;
         }
+        if (p.bg_kernel)  // the background tiles of a high-spp frame from their streams in HBM
+            hipLaunchKernelGGL(background_kernel, dim3(batch_tiles < kQueueGrid ? batch_tiles : kQueueGrid), dim3(kBlock), 0, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
         const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
         if (p.scene_in_lds && !p.scene_posed) {
             hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);

@@ -248,3 +248,20 @@ def test_big_texture_pool_stays_in_hbm(mcrt, gpu, oracle):
     sd = mcrt.SceneDesc(scenes.simple_scene([inner, outer], light=(0, 40, 30), cam_pos=(0, 18, 40), bg=(0.2, 0.3, 0.5, 1.0)))
     cfg = abi.Config(width=80, height=60, maxBounces=2, samplesPerPixel=2)
     scenes.assert_bit_equal(mcrt.TileRenderer.render(sd, cfg), oracle.render(sd.ptr, cfg), "big texture")
+
+
+@pytest.mark.parametrize("spp,dof,tile", [(33, False, 32), (37, True, 32), (64, False, 24), (64, True, 32), (70, False, 50), (48, True, 7)])
+def test_high_sample_counts_take_the_slab_background_kernel(mcrt, oracle, gpu, spp, dof, tile):
+    """From 33 samples per pixel the background tiles are rendered by `background_kernel`: a wave stages slabs of 64 pixels x
+    16 samples of the tile's stream in LDS (coalesced), a lane per pixel consumes them in sample order.  Sample counts that are
+    no multiple of the slab, clipped and odd-sized tiles, depth of field (the stream then holds the jitter pairs only)."""
+    import scenes
+
+    sd = scenes.skin_scene("S64", 3)
+    kw = dict(width=150, height=100, maxBounces=2, samplesPerPixel=spp, tileSize=tile)
+    if dof:
+        kw.update(dofEnabled=True, aperture=0.3)
+    cfg = mcrt.Config(**kw)
+    img = mcrt.TileRenderer.render(sd, cfg)
+    assert mcrt.TileRenderer.lastErrors() == []
+    scenes.assert_bit_equal(img, oracle.render(sd.ptr, cfg), f"spp {spp} dof {dof} tile {tile}")
