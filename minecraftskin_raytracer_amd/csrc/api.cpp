@@ -139,6 +139,7 @@ struct mcrt_scene {
     // One handle = one frame in flight: all renders of a handle share its workspace.  `last_done` is recorded
     // at the end of every render; a render enqueued on a different stream than the previous one waits for it.
     hipEvent_t last_done = nullptr;
+    std::atomic<hipEvent_t> busy_probe{nullptr};  // = last_done once it exists: what OTHER handles' renders query (device_shared)
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     bool flags_checked = true;  // no render since mcrt_scene_check last read (and cleared) the lanes' overflow words
@@ -414,6 +415,40 @@ int launch_lanes(mcrt_scene* s, const RenderParams* p, int n_lanes, hipStream_t 
     return MCRT_OK;
 }
 
+// Every shell of the process (pooled ones included).  A render sizes its launches by whether its device is busy with
+// another handle's frame at the moment it is enqueued (choose_grids): it asks the other shells' last-render events.
+std::mutex g_live_mutex;
+std::vector<mcrt_scene*> g_live;
+void register_live(mcrt_scene* s) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    g_live.push_back(s);
+}
+void unregister_live(mcrt_scene* s) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), s), g_live.end());
+}
+bool device_shared(const mcrt_scene* s) {
+    static const int forced = [] {  // development knob: MCRT_SHARED_GRIDS=0 / 1 fixes the answer
+        const char* e = std::getenv("MCRT_SHARED_GRIDS");
+        return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+    }();
+    if (forced >= 0) return forced != 0;
+    bool shared = false;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        for (const mcrt_scene* q : g_live) {
+            if (q == s || q->device != s->device) continue;
+            hipEvent_t e = q->busy_probe.load(std::memory_order_acquire);
+            if (e && hipEventQuery(e) == hipErrorNotReady) {
+                shared = true;
+                break;
+            }
+        }
+    }
+    (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure of this render
+    return shared;
+}
+
 RngKey rng_key_of(const RenderParams& p) {
     RngKey k;
     k.ptr = p.tile_rng;
@@ -551,6 +586,14 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     if (n_lanes > 1 && !s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;  // the caller records a graph of its own
+    {  // Lanes share the device among themselves; a caller's graph is replayed in circumstances unknown now (no event queries
+       // while it records).  Frames of 2e7 samples and more (three lanes) keep the large grids: their kernels run for
+       // milliseconds, balance counts for more than room for the neighbours (GUI defaults 3.14 / 3.20 ms, 8K 17.9 / 18.0).
+        const int spp = cfg->samples_per_pixel > 1 ? cfg->samples_per_pixel : 1;
+        const double samples = static_cast<double>(whole.owned_rows) * cfg->tile_size * cfg->width * spp;
+        const bool shared = samples < 2.0e7 && (n_lanes > 1 || (!capturing && device_shared(s)));
+        for (int li = 0; li < n_lanes; ++li) choose_grids(p[li], shared);
+    }
     if (capturing && groups) return fail(MCRT_ERR_INVALID, "row-group events cannot be recorded into a caller's graph");
     // all renders of a handle share its workspace: they run one after the other whatever streams they are given
     if (!capturing && s->have_last && s->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, s->last_done, 0));
@@ -565,7 +608,10 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
         HIP_TRY(launch_seed_tiles(p[li], stream));
         ln.rng_key = capturing ? RngKey{} : k;  // a captured seeding pass runs when the caller's graph does, not now
     }
-    if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
+    if (!s->last_done) {
+        HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
+        s->busy_probe.store(s->last_done, std::memory_order_release);
+    }
     int rc;
     if (groups) {
         // which rows are final when: a row that holds no touched tile is complete behind plan_tiles (which
@@ -855,6 +901,7 @@ int create_scene_from_blob(const std::vector<uint8_t>& b, int device, mcrt_scene
     if (!s) {
         s = new mcrt_scene();
         s->device = device;
+        register_live(s);
     }
     s->forced_lanes = 0;
     s->budget = 0;  // a budget halved under memory pressure is not inherited
@@ -931,6 +978,7 @@ void mcrt_trim(void) {
 namespace {
 void destroy_scene_now(mcrt_scene* s) {
     if (!s) return;
+    unregister_live(s);  // before its events go
     if (s->holds_seed_table) release_seed_table(s->device);
     if (s->holds_full_table) release_full_seed_table(s->device);
     s->blob.release();  // the other buffers are released by their destructors below

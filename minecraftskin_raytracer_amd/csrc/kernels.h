@@ -116,6 +116,10 @@ struct RenderParams {
                            //    rt::mesh_candidate_inside (the exit face alone); 0 (MCRT_INSIDE_FAST=0) — the general routine
     int bundle_decisions;  // `lit`: 1 — a hit whose whole bundle of shadow rays is decided (rt::bundle_decide) draws no light
                            //    samples and traces no rays; 0 (MCRT_BUNDLE_DECISIONS=0) — every hit's rays are traced
+    int shared_device;     // 1: this render shares the device with others (another lane of its frame, or another handle's frame still
+                           //    running when it was enqueued): the grids below are then sized for throughput — fewer, longer-lived
+                           //    workgroups per kernel leave room for the other frames' kernels —, otherwise for the frame's own latency
+    int grid_primary, grid_chase, grid_ao, grid_lit, grid_resolve;  // workgroup caps of the launches (choose_grids; all kernels stride)
     int rect_x, rect_y, rect_w, rect_h;  // rect_w > 0: the launch renders ONE tile, this rectangle (TileRenderer::renderTile for an
                            //    arbitrary Tile, tile_renderer.cpp:71-127: seed rect_y * width + rect_x, pixels in the rectangle's own
                            //    row-major order); the shard is then one tile row of one tile
@@ -131,6 +135,8 @@ struct WorkspaceBytes {
 };
 // row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
 WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);
+// fills p.shared_device and p.grid_* (MCRT_*_GRID override single grids, development knobs)
+void choose_grids(RenderParams& p, bool shared_device);
 constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
 constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
 constexpr int kCounterWords = 4096;

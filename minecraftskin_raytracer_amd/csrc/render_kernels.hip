@@ -68,6 +68,9 @@ constexpr int kChunk = 256;        // work items per chunk: one per thread
 #endif
 constexpr int kPrimaryGrid = MCRT_PRIMARY_GRID; // persistent primary workgroups (5 per CU: the kernel is built for 5 waves per SIMD)
 constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
+constexpr int kLitGridAlone = 4096;  // `lit` of a frame that has the device to itself
+constexpr int kResolveGrid = 4096;
+constexpr int kSharedGrid = 1024;  // every kernel of a frame that shares the device (choose_grids)
 
 // n / d for a divisor that is the same for the whole wave: a shift when it is a power of two (tile widths of 32,
 // 4 samples per pixel: the usual case) instead of the ~25-instruction expansion of a 32-bit division.
@@ -1943,6 +1946,30 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     return w;
 }
 
+static int grid_knob(const char* name, int fallback) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : fallback;
+}
+
+// Workgroup caps of a render's launches.  Every kernel strides over device-side counts, so a cap changes nothing but
+// the schedule.  A frame alone on the device finishes soonest with many workgroups per kernel (`lit`'s rounds differ in
+// cost: 16 per CU balance better than 8, -7 us); frames that share the device — four handles in flight, or the lanes of
+// one large frame — get through fastest with FEWER workgroups per kernel (4 per CU), which leaves CU slots to the other
+// frames' kernels instead of queueing whole kernels behind each other (+4 % frames/s at 1080p; profiles/r03_experiments/grid_sweep*.txt).
+void choose_grids(RenderParams& p, bool shared_device) {
+    static const int queue_knob = grid_knob("MCRT_QUEUE_GRID", 0);
+    static const int primary_knob = grid_knob("MCRT_PRIMARY_GRID", 0), chase_knob = grid_knob("MCRT_CHASE_GRID", queue_knob),
+                     ao_knob = grid_knob("MCRT_AO_GRID", queue_knob), lit_knob = grid_knob("MCRT_LIT_GRID", queue_knob),
+                     resolve_knob = grid_knob("MCRT_RESOLVE_GRID", 0);
+    p.shared_device = shared_device ? 1 : 0;
+    p.grid_primary = primary_knob ? primary_knob : (shared_device ? kSharedGrid : kPrimaryGrid);
+    p.grid_chase = chase_knob ? chase_knob : (shared_device ? kSharedGrid : kQueueGrid);
+    p.grid_ao = ao_knob ? ao_knob : (shared_device ? kSharedGrid : kQueueGrid);
+    p.grid_lit = lit_knob ? lit_knob : (shared_device ? kSharedGrid : kLitGridAlone);
+    p.grid_resolve = resolve_knob ? resolve_knob : (shared_device ? kSharedGrid : kResolveGrid);
+}
+
 template <int kView>
 static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn) {
     const mcrt_config& c = p.cfg;
@@ -1960,17 +1987,13 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         }
         return;
     }
-    static const int grid = [] {  // development knob
-        const char* e = getenv("MCRT_QUEUE_GRID");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : kQueueGrid;
-    }();
+    const int chase_grid = p.grid_chase > 0 ? p.grid_chase : kQueueGrid, ao_grid = p.grid_ao > 0 ? p.grid_ao : kQueueGrid, lit_grid = p.grid_lit > 0 ? p.grid_lit : kQueueGrid;
     if (levels >= 2)  // the chains below the level-1 records `primary` found (maxBounces = 0: it has marked the chains already)
-        hipLaunchKernelGGL(chase_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
+        hipLaunchKernelGGL(chase_kernel<kView>, dim3(chase_grid), dim3(kBlock), dyn, stream, p.scene, p);
     if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
-        hipLaunchKernelGGL(ao_kernel<kView>, dim3(grid), dim3(kBlock), dyn, stream, p.scene, p);
+        hipLaunchKernelGGL(ao_kernel<kView>, dim3(ao_grid), dim3(kBlock), dyn, stream, p.scene, p);
     }
-    hipLaunchKernelGGL(lit_kernel<kView>, dim3(grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);
+    hipLaunchKernelGGL(lit_kernel<kView>, dim3(lit_grid), dim3(kBlock), static_cast<size_t>(p.lit_lds_offset) + static_cast<size_t>(p.lit_lds_bytes), stream, p.scene, p);
 }
 
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
@@ -2005,7 +2028,8 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
         }
         if (p.bg_kernel)  // the background tiles of a high-spp frame from their streams in HBM
             hipLaunchKernelGGL(background_kernel, dim3(batch_tiles < kQueueGrid ? batch_tiles : kQueueGrid), dim3(kBlock), 0, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
-        const int pgrid = batch_tiles * p.parts_per_tile < kPrimaryGrid ? batch_tiles * p.parts_per_tile : kPrimaryGrid;
+        const int primary_grid = p.grid_primary > 0 ? p.grid_primary : kPrimaryGrid, resolve_grid = p.grid_resolve > 0 ? p.grid_resolve : kResolveGrid;
+        const int pgrid = batch_tiles * p.parts_per_tile < primary_grid ? batch_tiles * p.parts_per_tile : primary_grid;
         if (p.scene_in_lds && !p.scene_posed) {
             hipLaunchKernelGGL(primary_kernel<kViewLdsUnposed>, dim3(pgrid), dim3(kBlock), dyn, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewLdsUnposed>(p, stream, dyn);
@@ -2016,7 +2040,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
             hipLaunchKernelGGL(primary_kernel<kViewHbm>, dim3(pgrid), dim3(kBlock), 0, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
             launch_levels<kViewHbm>(p, stream, 0);
         }
-        const int rgrid = batch_tiles * p.parts_per_tile < 4096 ? batch_tiles * p.parts_per_tile : 4096;
+        const int rgrid = batch_tiles * p.parts_per_tile < resolve_grid ? batch_tiles * p.parts_per_tile : resolve_grid;
         hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, p.scene, out, out8, p);
         const int batch = r0 / p.rows_per_batch;
         if (marks && batch < marks->n_batch_done) {

@@ -450,3 +450,33 @@ def test_workspace_is_reused_across_scenes_and_trim_frees_it(mcrt, gpu, oracle):
     mcrt.trim()
     free3, _ = torch.cuda.mem_get_info()
     assert free3 > free1 + (30 << 20)
+
+
+def test_frames_in_flight_on_one_device_render_the_same_bits(mcrt, gpu, oracle):
+    """A render enqueued while another handle's frame is still running on the device sizes its launches for sharing
+    (fewer workgroups per kernel, api.cpp device_shared / choose_grids), one enqueued on an idle device for its own
+    latency; both are recorded as launch graphs of their own.  The schedule must not show in the pixels."""
+    sd = scenes.skin_scene("S64", 6)
+    cfg = abi.Config(width=480, height=272, maxBounces=3, samplesPerPixel=2)
+    want = oracle.render(sd.ptr, cfg)
+    handles = [mcrt.DeviceScene(sd) for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in handles]
+    outs = [torch.zeros((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda") for _ in handles]
+    for rep in range(8):  # in flight together: all but the very first enqueue find the device busy
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        for ds, st, o in zip(handles, streams, outs):
+            ds.render_device(cfg, o.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            scenes.assert_bit_equal(o.cpu().numpy(), want, f"round {rep}, handle {i} (frames in flight)")
+    for rep in range(6):  # one at a time: idle device
+        for i, (ds, st, o) in enumerate(zip(handles, streams, outs)):
+            o.zero_()
+            ds.render_device(cfg, o.data_ptr(), 0, 1, abi.LAYOUT_FRAME, st.cuda_stream)
+            torch.cuda.synchronize()
+            scenes.assert_bit_equal(o.cpu().numpy(), want, f"round {rep}, handle {i} (alone)")
+    for ds in handles:
+        ds.check()
+        ds.close()

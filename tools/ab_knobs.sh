@@ -10,7 +10,7 @@ STEPS=${AB_STEPS:-150}
 for spec in "$@"; do
   label=${spec%%|*}; envs=${spec#*|}
   [ "$envs" = "$spec" ] && envs=""
-  line=$(env $envs timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --steps $STEPS --workload $WORKLOAD 2>/dev/null | python3 -c "
+  line=$(env $envs timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --steps $STEPS --workload $WORKLOAD ${AB_ARGS:-} 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print(d['value'], d['ms_per_step'], d['latency_ms'], d['kernel']['pipeline_ms'], (d.get('render_call') or {}).get('ms'))")
