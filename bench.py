@@ -493,7 +493,7 @@ def main() -> None:
             "latency_mpixels_per_s": round(w * h / latency_ms / 1e3, 2),
             "kernel": {"pipeline_ms": round(pipeline_ms, 4),
                        "note": "hipEvents on the launch stream around one frame's whole pipeline on one stream (counter memset, plan_tiles, "
-                               "primary, chase, [ao,] lit, resolve)"},
+                               "primary, [ao,] lit, resolve)"},
             "roofline": roof,
         }
         if render_call is not None:

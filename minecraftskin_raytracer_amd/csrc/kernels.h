@@ -61,7 +61,7 @@ struct WaveSpace {
                             // hits (general variants: ping-pong by level parity, [cap] each)
     float4* stack;          // [stack_stride][cap] level colours of the chains, plane-major: depth d of the chain of sample slot r
                             // at [d * cap + r] — the level-0 colours of neighbouring samples share cache lines
-    uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [2] records of levels >= 2, [8 + L] entries of level L >= 1
+    uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [8 + L] entries of level L >= 1
                             // ([9] = level-1 records), [last] touched-tile bound exceeded (never, by construction; sticky);
                             // cleared per pass but for the last
     uint32_t* hit_rng;      // general variants: per-thread 624-word mt19937 states (long streams)
@@ -119,7 +119,7 @@ struct RenderParams {
     int shared_device;     // 1: this render shares the device with others (another lane of its frame, or another handle's frame still
                            //    running when it was enqueued): the grids below are then sized for throughput — fewer, longer-lived
                            //    workgroups per kernel leave room for the other frames' kernels —, otherwise for the frame's own latency
-    int grid_primary, grid_chase, grid_ao, grid_lit, grid_resolve;  // workgroup caps of the launches (choose_grids; all kernels stride)
+    int grid_primary, grid_ao, grid_lit, grid_resolve;  // workgroup caps of the launches (choose_grids; all kernels stride)
     int rect_x, rect_y, rect_w, rect_h;  // rect_w > 0: the launch renders ONE tile, this rectangle (TileRenderer::renderTile for an
                            //    arbitrary Tile, tile_renderer.cpp:71-127: seed rect_y * width + rect_x, pixels in the rectangle's own
                            //    row-major order); the shard is then one tile row of one tile
@@ -145,7 +145,7 @@ constexpr int kCounterWords = 4096;
 // tile size and the shard only — the caller keeps the result across renders and calls this when those change.
 hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream);
 // enqueue the whole pipeline of one lane on `stream` (p.tile_rng already seeded): per batch of tile rows
-// plan → primary (+ the primary hits' reflection rays) → chase → (ao →) lit → resolve
+// plan → primary (+ the primary hits' reflection rays) → (ao →) lit (the rest of the chains, then light and shade) → resolve
 // Optional events for a caller that downloads tile rows as they become final (the one-shot host path):
 //  after_plan    recorded behind the first pass's plan_tiles: with bg_in_plan every tile row that holds no touched
 //                tile is complete then

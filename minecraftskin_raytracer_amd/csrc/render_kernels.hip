@@ -19,12 +19,13 @@
 //                                     ... and, packed on the block's first threads, the reflection ray of every
 //                                     primary hit (geometry only: direction, hit point, normal) → closest hit →
 //                                     level-1 record; chains that end are marked
-//   chase           1 lane / level-1 record        the rest of the chain: reflect, closest hit, append, until the ray
-//                                     misses or maxBounces is reached (~10 % go on per level)
 //   ... then ONCE over the records of ALL levels (320 k + 31 k + 3 k + ... at 1080p / 4 spp):
 //   ao              (AO on) 1 lane / primary hit   the meshes its hemisphere of rays can meet; mt19937(ao seed), the A
 //                                     cosine-weighted directions and their any-hit tests within the radius, in registers
-//   lit             phases per block of 256 records, handed over through LDS:
+//   lit             first, per block of 256 level-1 records (1 lane / record): the rest of the chain — reflect, closest
+//                                     hit, append, until the ray misses or maxBounces is reached (~10 % go on per level) —
+//                                     into a region of the queue the block owns, lit and shaded by the same workgroup;
+//                   then phases per block of 256 records, handed over through LDS:
 //                   1 lane / record   the hit's bundle mask (meshes its shadow rays can meet) and the whole-bundle
 //                                     decision (rt::bundle_classify): most hits are provably lit by all S light
 //                                     samples or by none and need no samples and no rays; the rest are packed
@@ -34,7 +35,7 @@
 //   resolve         1 lane / pixel    folds each sample's chain back to front, ordered sum of the pixel's sample
 //                                     colours (float addition order is part of the result), coalesced float4 / RGBA8 store
 //   (general variants — per-hit RNG streams longer than 227 draws, or more than kFlatMaxBounces bounces — run
-//   light_samples / shadow / level_shade once per recursion level instead of chase and lit, and `primary` traces no
+//   light_samples / shadow / level_shade once per recursion level instead of lit, and `primary` traces no
 //   reflection rays)
 // Records live in HBM as SoA float4 arrays.  Every unit owns a fixed slot range (its samples); its
 // primary hits are compacted to the front of that range with an LDS prefix sum and a per-unit count —
@@ -424,7 +425,6 @@ struct ViewSel<kViewHbm> {
 // counters[0]: number of planned units (one atomic add per touched tile, in plan_tiles)
 constexpr int kCntDense = 8;              // general variants: counters[kCntDense + L] = entries of level L >= 1
 constexpr int kCntDeep1 = kCntDense + 1;  // flat pipeline: level-1 records
-constexpr int kCntDeep2 = 2;              // flat pipeline: records of levels >= 2
 // WaveSpace::end of a sample whose chain has ended: (records of the chain << 1) | stopped at maxBounces
 __device__ __forceinline__ uint32_t chain_code(int records, bool stopped_at_max) {
     return (static_cast<uint32_t>(records) << 1) | (stopped_at_max ? 1u : 0u);
@@ -885,15 +885,15 @@ __global__ __launch_bounds__(kBlock) void background_kernel(const uint8_t* __res
 // The recursion of RayTracer::traceRay (raytracer.cpp:82-148) as a FLAT pipeline.  The reflection ray
 // of a hit depends on geometry only — direction, hit point, normal (:133-139) — not on the colour
 // of the hit.  So the chain of hits below a primary hit is chased first (`primary`'s second phase: every
-// primary hit's reflection ray; `chase`: the ~10 % that hit again, followed to their end), every hit of every
+// primary hit's reflection ray; the head of `lit`: the ~10 % that hit again, followed to their end), every hit of every
 // level becoming one *record*; then the expensive stages — light samples, shadow rays, shading — run ONCE over
 // all records of all levels, and `resolve` folds each chain's level colours back to front (:143-147)
 // while it sums the pixel's samples.  One launch set per level cost ~40 us of dependent latency per
 // level whatever it held (320 k, 31 k, 3 k, 300, 30 records at 1080p / 4 spp).
 //
-// Primary hits sit at the front of each unit's slot range (count per unit, no atomics).  Deeper records
-// are appended densely behind index `cap` with ONE workgroup-aggregated atomic per 256-entry block:
-// level 1 by `primary` (counter kCntDeep1), levels >= 2 by `chase` behind them (kCntDeep2).
+// Primary hits sit at the front of each unit's slot range (count per unit, no atomics).  Level-1 records are
+// appended densely behind index `cap` by `primary` with ONE workgroup-aggregated atomic per 256-entry block (counter
+// kCntDeep1); the records of levels >= 2 go to per-block regions behind them and never meet a global counter (`lit`).
 // The general variants (per-hit RNG streams longer than the register engine, or more bounces than
 // the flat record arrays are laid out for) keep one launch set per level with ping-pong queues.
 // ---------------------------------------------------------------------------------------------
@@ -907,7 +907,7 @@ struct Scope {
     __device__ __forceinline__ int par() const { return flat ? 0 : (level & 1); }
 };
 __device__ __forceinline__ uint32_t dense_count(const WaveSpace& ws, Scope s) {
-    return s.flat ? ws.counters[kCntDeep1] + ws.counters[kCntDeep2] : ws.counters[kCntDense + s.level];
+    return s.flat ? ws.counters[kCntDeep1] : ws.counters[kCntDense + s.level];  // (flat: the level-1 records; deeper ones are private to `lit`'s chasing blocks)
 }
 __device__ __forceinline__ uint32_t dense_base(const WaveSpace& ws, Scope s) { return s.flat ? ws.cap : 0u; }
 
@@ -962,73 +962,6 @@ __device__ __forceinline__ Record load_record(const WaveSpace& ws, int par, uint
         r.hit.tex = C4{qt.x, qt.y, qt.z, qt.w};
     }
     return r;
-}
-
-#ifndef MCRT_BOUNCE_WAVES
-#define MCRT_BOUNCE_WAVES 4
-#endif
-// ---------------------------------------------------------------------------------------------
-// chase: every level-1 record's chain followed to its end, a lane per chain — reflect, closest hit,
-// append the record — until the ray misses or the chain reaches maxBounces.  ~10 % of the lanes go on per
-// turn; the loop is workgroup-uniform (it ends when no lane of the block goes on).
-// ---------------------------------------------------------------------------------------------
-template <int kView>
-__global__ __launch_bounds__(kBlock, MCRT_BOUNCE_WAVES) void chase_kernel(const uint8_t* __restrict__ scene_blob, const RenderParams p) {
-    __shared__ int s_wcnt[kBlock / 64];
-    __shared__ uint32_t s_out_base;
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    const SceneView scg = view_of(scene_blob);
-    const WaveSpace& ws = p.ws;
-    const uint32_t count1 = ws.counters[kCntDeep1];
-    if (static_cast<unsigned long long>(blockIdx.x) * kBlock >= count1) return;  // before the collective staging
-    const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
-    const int max_b = p.cfg.max_bounces;
-    const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
-    const uint32_t deep2_base = ws.cap + count1;  // records of levels >= 2 go behind the level-1 records
-    for_each_dense_block(ws.cap, count1, [&](uint32_t first, uint32_t n) __attribute__((always_inline)) {
-        bool active = threadIdx.x < n;
-        RecordGeom r;
-        r.root = 0;
-        r.depth = 1;
-        r.d = mk(0, 0, 0);
-        r.p = mk(0, 0, 0);
-        r.n = mk(0, 0, 0);
-        if (active) r = load_geom(ws, posed, first + threadIdx.x);
-        for (;;) {
-            bool next_hit = false;
-            Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
-            Hit nhit;
-            nhit.hit = false;
-            if (active) {
-                if (r.depth >= max_b) {  // no reflection at the last level
-                    ws.end[r.root] = chain_code(r.depth + 1, true);
-                    active = false;
-                } else {
-                    nray = reflect_ray(r.d, r.p, r.n);
-                    nhit = hit_scene<true>(sc, nray, ~0ull);
-                    if (nhit.hit) {
-                        next_hit = true;
-                    } else {
-                        ws.end[r.root] = chain_code(r.depth + 1, false);
-                        active = false;
-                    }
-                }
-            }
-            int total = 0;
-            const int rank = block_rank(next_hit, s_wcnt, total);
-            if (total == 0) break;  // uniform: no chain of this block goes on
-            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep2], static_cast<uint32_t>(total));
-            __syncthreads();
-            if (next_hit) {
-                push_record(ws, posed, deep2_base + s_out_base + static_cast<uint32_t>(rank), nray, nhit, r.root, r.depth + 1, true);
-                r.d = nray.d;
-                r.p = nhit.p;
-                r.n = nhit.n;
-                ++r.depth;
-            }
-            __syncthreads();
-        }
-    });
 }
 
 // The S light sample positions of one hit: mt19937(shadow seed) → 2·S draws → disk samples
@@ -1217,7 +1150,17 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const uint32_t n_units = ws.counters[kCntUnits];
     const uint32_t n_dense = dense_count(ws, scope);
     const uint32_t n_items = n_units + (n_dense + kBlock - 1u) / kBlock;
-    if (blockIdx.x >= n_items) return;  // before the collective staging
+    // The chase: the chains below the level-1 records are followed HERE, ahead of the work list — a block of 256
+    // level-1 records per workgroup turn, a lane per chain — and the records they append (levels >= 2) go to a region
+    // of the dense queue that belongs to that block alone: no global counter, and no other workgroup ever waits for
+    // them.  The workgroup that made them lights and shades them itself, as one more (sparse) entry of its work list.
+    // (As a launch of its own between `primary` and `lit` the chase was 32 us of a lone frame's 225 for 2 us of work —
+    // three dependent scene queries on 122 workgroups; in here it costs `lit` 5.)
+    const int max_b = p.cfg.max_bounces;
+    const uint32_t count1 = ws.counters[kCntDeep1];
+    const uint32_t n_chase = max_b >= 1 ? (count1 + kBlock - 1u) / kBlock : 0u;
+    const uint32_t n_work = n_chase + n_items;
+    if (blockIdx.x >= n_work) return;  // before the collective staging
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     constexpr bool kPosed = kView != kViewLdsUnposed;
     const int mode = shadow_mode(scg, p.cfg);
@@ -1238,13 +1181,62 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const bool posed = kView != kViewLdsUnposed && p.scene_posed != 0;  // the un-posed variants never read q_n
     const bool dof = cfg.dof_enabled && cfg.aperture > 1e-6f;
     const V3 cam_pos = ld3(scg.hdr->cam_pos);
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    for (uint32_t work = blockIdx.x; work < n_work; work += gridDim.x) {
         uint32_t first, n;
-        if (item < n_units) {
-            first = ws.units[item].w;
-            n = ws.unit_hits[item];
+        if (work < n_chase) {
+            // the chains of level-1 records [k0, k0 + 256): a lane per chain — reflect, closest hit, append — until the ray
+            // misses or the chain reaches maxBounces; ~10 % of the lanes go on per turn, the loop is workgroup-uniform
+            const uint32_t k0 = work * kBlock;
+            const uint32_t region = ws.cap + n_chase * kBlock + k0 * static_cast<uint32_t>(max_b - 1);  // 256 x (maxBounces - 1) slots per block
+            uint32_t filled = 0;  // uniform
+            bool active = k0 + threadIdx.x < count1;
+            RecordGeom r;
+            r.root = 0;
+            r.depth = 1;
+            r.d = mk(0, 0, 0);
+            r.p = mk(0, 0, 0);
+            r.n = mk(0, 0, 0);
+            if (active) r = load_geom(ws, posed, ws.cap + k0 + threadIdx.x);
+            for (;;) {
+                bool next_hit = false;
+                Ray nray{mk(0, 0, 0), mk(0, 0, 0)};
+                Hit nhit;
+                nhit.hit = false;
+                if (active) {
+                    if (r.depth >= max_b) {  // no reflection at the last level
+                        ws.end[r.root] = chain_code(r.depth + 1, true);
+                        active = false;
+                    } else {
+                        nray = reflect_ray(r.d, r.p, r.n);
+                        nhit = hit_scene<true>(sc, nray, ~0ull);
+                        if (nhit.hit) {
+                            next_hit = true;
+                        } else {
+                            ws.end[r.root] = chain_code(r.depth + 1, false);
+                            active = false;
+                        }
+                    }
+                }
+                int total = 0;
+                const int rank = block_rank(next_hit, s_wcnt, total);
+                if (total == 0) break;  // uniform: no chain of this block goes on
+                if (next_hit) {
+                    push_record(ws, posed, region + filled + static_cast<uint32_t>(rank), nray, nhit, r.root, r.depth + 1, true);
+                    r.d = nray.d;
+                    r.p = nhit.p;
+                    r.n = nhit.n;
+                    ++r.depth;
+                }
+                filled += static_cast<uint32_t>(total);
+            }
+            __syncthreads();  // the block's own records, written by other lanes than the ones that read them below
+            first = region;
+            n = filled;
+        } else if (work - n_chase < n_units) {
+            first = ws.units[work - n_chase].w;
+            n = ws.unit_hits[work - n_chase];
         } else {
-            const uint32_t k0 = (item - n_units) * kBlock;
+            const uint32_t k0 = (work - n_chase - n_units) * kBlock;
             first = ws.cap + k0;
             n = min(static_cast<uint32_t>(kBlock), n_dense - k0);
         }
@@ -1923,7 +1915,8 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     if (tile_slots == 0 || cap_tiles > index_limit / tile_slots || draws_stride > 0xffff0000ull)
         p.rows_per_batch = 0;  // one tile (row) alone exceeds the 32-bit index ranges: refused by the caller
     const size_t cap = p.rows_per_batch ? cap_tiles * tile_slots : 1;
-    const size_t rec_cap = cap * recs;
+    // (+ 256 x recs: `lit`'s chase regions start at the level-1 count rounded up to a whole block)
+    const size_t rec_cap = cap * recs + (p.flat ? static_cast<size_t>(kBlock) * recs : 0);
     p.ws.cap = static_cast<uint32_t>(cap);
     p.ws.tile_cap = static_cast<uint32_t>(cap_tiles);
     w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 : 0;
@@ -1959,12 +1952,11 @@ static int grid_knob(const char* name, int fallback) {
 // frames' kernels instead of queueing whole kernels behind each other (+4 % frames/s at 1080p; profiles/r03_experiments/grid_sweep*.txt).
 void choose_grids(RenderParams& p, bool shared_device) {
     static const int queue_knob = grid_knob("MCRT_QUEUE_GRID", 0);
-    static const int primary_knob = grid_knob("MCRT_PRIMARY_GRID", 0), chase_knob = grid_knob("MCRT_CHASE_GRID", queue_knob),
+    static const int primary_knob = grid_knob("MCRT_PRIMARY_GRID", 0),
                      ao_knob = grid_knob("MCRT_AO_GRID", queue_knob), lit_knob = grid_knob("MCRT_LIT_GRID", queue_knob),
                      resolve_knob = grid_knob("MCRT_RESOLVE_GRID", 0);
     p.shared_device = shared_device ? 1 : 0;
     p.grid_primary = primary_knob ? primary_knob : (shared_device ? kSharedGrid : kPrimaryGrid);
-    p.grid_chase = chase_knob ? chase_knob : (shared_device ? kSharedGrid : kQueueGrid);
     p.grid_ao = ao_knob ? ao_knob : (shared_device ? kSharedGrid : kQueueGrid);
     p.grid_lit = lit_knob ? lit_knob : (shared_device ? kSharedGrid : kLitGridAlone);
     p.grid_resolve = resolve_knob ? resolve_knob : (shared_device ? kSharedGrid : kResolveGrid);
@@ -1987,9 +1979,7 @@ static void launch_levels(const RenderParams& p, hipStream_t stream, size_t dyn)
         }
         return;
     }
-    const int chase_grid = p.grid_chase > 0 ? p.grid_chase : kQueueGrid, ao_grid = p.grid_ao > 0 ? p.grid_ao : kQueueGrid, lit_grid = p.grid_lit > 0 ? p.grid_lit : kQueueGrid;
-    if (levels >= 2)  // the chains below the level-1 records `primary` found (maxBounces = 0: it has marked the chains already)
-        hipLaunchKernelGGL(chase_kernel<kView>, dim3(chase_grid), dim3(kBlock), dyn, stream, p.scene, p);
+    const int ao_grid = p.grid_ao > 0 ? p.grid_ao : kQueueGrid, lit_grid = p.grid_lit > 0 ? p.grid_lit : kQueueGrid;
     if (c.ao_enabled && c.ao_samples > 0) {  // ahead of `lit`, whose last phase applies the AO factor
         hipLaunchKernelGGL(ao_kernel<kView>, dim3(ao_grid), dim3(kBlock), dyn, stream, p.scene, p);
     }

@@ -265,3 +265,33 @@ def test_high_sample_counts_take_the_slab_background_kernel(mcrt, oracle, gpu, s
     img = mcrt.TileRenderer.render(sd, cfg)
     assert mcrt.TileRenderer.lastErrors() == []
     scenes.assert_bit_equal(img, oracle.render(sd.ptr, cfg), f"spp {spp} dof {dof} tile {tile}")
+
+
+@pytest.mark.parametrize("bounces,spp,size,tile", [(4, 2, (96, 64), 32), (8, 1, (70, 50), 16), (1, 3, (64, 48), 32), (3, 4, (50, 37), 7),
+                                                    (3, 2, (1920, 1080), 32)])  # the last: 16 000 blocks of level-1 records, more than any grid
+def test_closed_room_fills_every_chain_to_the_last_level(mcrt, oracle, gpu, bounces, spp, size, tile):
+    """The worst case the record queues are laid out for: the camera stands inside a closed room (one large box) with two
+    boxes in it, so every sample hits, every reflection hits again, and every chain runs to maxBounces.  `lit` follows the
+    chains of a block of 256 level-1 records into a region of 256 x (maxBounces - 1) slots that the block owns: here every
+    region is filled to its last slot (frame and tile sizes that leave partly filled blocks and units included)."""
+    wall = scenes.solid((0.7, 0.75, 0.8, 1.0))
+    room = scenes.build_box(wall, (0, 18, 0), (60, 40, 60))
+    a = scenes.build_box(scenes.solid((0.9, 0.2, 0.2, 1.0)), (-5, 8, -6), (8, 16, 8))
+    b = scenes.build_box(scenes.solid((0.2, 0.8, 0.3, 1.0)), (7, 5, 2), (6, 10, 6))
+    sc = scenes.simple_scene([room, a, b], light=(3, 34, 5), cam_pos=(2, 16, 24), cam_target=(0, 12, 0), radius=2.0)
+    sd = mcrt.SceneDesc(sc)
+    cfg = abi.Config(width=size[0], height=size[1], maxBounces=bounces, samplesPerPixel=spp, tileSize=tile)
+    want = oracle.render(sd.ptr, cfg)
+    scenes.assert_bit_equal(mcrt.TileRenderer.render(sd, cfg), want, f"closed room, {bounces} bounces")
+    ds = mcrt.DeviceScene(sd)
+    import torch
+
+    out = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda")
+    for lanes in (1, 3):  # and through the device entry point, alone and with lanes
+        ds.set_lanes(lanes)
+        out.zero_()
+        ds.render_device(cfg, out.data_ptr(), 0, 1, abi.LAYOUT_FRAME, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        scenes.assert_bit_equal(out.cpu().numpy(), want, f"closed room, {lanes} lane(s)")
+    ds.check()
+    ds.close()
