@@ -426,6 +426,7 @@ struct ViewSel<kViewHbm> {
 constexpr int kCntDense = 8;              // general variants: counters[kCntDense + L] = entries of level L >= 1
 constexpr int kCntDeep1 = kCntDense + 1;  // flat pipeline: level-1 records
 // WaveSpace::end of a sample whose chain has ended: (records of the chain << 1) | stopped at maxBounces
+constexpr uint32_t kEndMiss = 0xffffffffu;  // the primary ray missed: the sample's colour is the background at its jittered position
 __device__ __forceinline__ uint32_t chain_code(int records, bool stopped_at_max) {
     return (static_cast<uint32_t>(records) << 1) | (stopped_at_max ? 1u : 0u);
 }
@@ -701,18 +702,22 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
                 ray = dof ? lens_ray(sc, su, sv, aspect, cfg.aperture, focusDist, jd[dpos], jd[dpos + 1])
                           : camera_ray(sc, su, sv, aspect);
                 hit = hit_scene(sc, ray, mesh_mask);
-                C4 col;
-                if (!hit.hit)
-                    col = background(sc, cfg, su, sv);  // tile_renderer.cpp:111-114
-                else if (cfg.max_bounces < 0)
-                    col = background(sc, cfg, 0.5f, 0.5f);  // raytracer.cpp:86-90 (depth 0 > maxBounces)
-                else
+                // A miss: its colour is a function of the sample's jitter pair alone (tile_renderer.cpp:111-114) — `resolve`
+                // forms it from the pair in the tile's stream (8 B) instead of a colour stored here and read back there
+                // (2 x 16 B for each of the 1.35 M misses of the metric frame's touched tiles: 43 MB of its HBM traffic).
+                uint32_t code = kEndMiss;
+                if (hit.hit && cfg.max_bounces < 0) {
+                    const C4 col = background(sc, cfg, 0.5f, 0.5f);  // raytracer.cpp:86-90 (depth 0 > maxBounces)
+                    ws.scol[sample_slot] = make_float4(col.r, col.g, col.b, col.a);
+                    code = 0u;
+                } else if (hit.hit) {
                     is_hit = true;
-                if (!is_hit) ws.scol[sample_slot] = make_float4(col.r, col.g, col.b, col.a);  // final for misses
-                // 0: the colour is in scol (general variants: `level_shade` puts the hits' colours there too).  Flat
-                // pipeline: the second phase below / `chase` overwrite a hit's word with its chain's end code — unless
-                // maxBounces is 0 and the chain is its primary hit alone.
-                ws.end[sample_slot] = (is_hit && p.flat && cfg.max_bounces == 0) ? 3u : 0u;
+                    // 0: the colour is in scol (general variants: `level_shade` puts the hits' colours there).  Flat pipeline:
+                    // the second phase below / `lit` overwrite a hit's word with its chain's end code — unless maxBounces is 0
+                    // and the chain is its primary hit alone.
+                    code = (p.flat && cfg.max_bounces == 0) ? 3u : 0u;
+                }
+                ws.end[sample_slot] = code;
             }
             // hits → dense entries at the front of the unit's slot range (no global atomics)
             int total = 0;
@@ -1539,8 +1544,7 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
 // missed (:94-102), the clamped last level colour when it stopped at maxBounces (:146-147).
 // A thread per SAMPLE fetches / folds the colour; the pixel's samples meet in LDS and one thread per
 // pixel adds them in order (float addition order is part of the result).
-__device__ __forceinline__ float4 sample_colour(const WaveSpace& ws, uint32_t slot, const C4& flat_bg) {
-    const uint32_t code = ws.end[slot];
+__device__ __forceinline__ float4 sample_colour(const WaveSpace& ws, uint32_t slot, uint32_t code, const C4& flat_bg) {
     if (code == 0u) return ws.scol[slot];
     const float4* lv = ws.stack + slot;  // level d of the chain: lv[d * cap]
     const size_t plane = ws.cap;
@@ -1557,16 +1561,35 @@ __device__ __forceinline__ float4 sample_colour(const WaveSpace& ws, uint32_t sl
     }
     return make_float4(tail.r, tail.g, tail.b, tail.a);
 }
-__global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restrict__ scene_blob, float4* __restrict__ out_frame,
-                                                         uchar4* __restrict__ out8, const RenderParams p) {
+__global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restrict__ scene_blob, const float* __restrict__ tile_draws,
+                                                         float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p,
+                                                         const int tile_base) {
     __shared__ float4 s_col[kBlock];
     const WaveSpace& ws = p.ws;
     const mcrt_config& cfg = p.cfg;
+    const SceneView scg = view_of(scene_blob);
+    const FrameDiv fd(p);
+    const uint32_t dd = static_cast<uint32_t>(p.draws_per_sample);
+    // the colour of sample `sidx` (stream order) of unit d: a miss from its jitter pair — the expressions of `primary`'s
+    // sample loop (tile_renderer.cpp:93-114) — else the chain's fold
+    auto unit_sample = [&](const uint4& d, const TileGeom& tg, const float* draws, uint32_t sidx, uint32_t spp_) __attribute__((always_inline)) -> float4 {
+        const uint32_t slot = d.w + sidx;
+        const uint32_t code = ws.end[slot];
+        if (code != kEndMiss) return sample_colour(ws, slot, code, C4{scg.hdr->background[0], scg.hdr->background[1], scg.hdr->background[2], scg.hdr->background[3]});
+        const unsigned pix = d.y + UDiv(spp_).div(sidx);
+        const unsigned uly = UDiv(static_cast<unsigned>(tg.w)).div(pix);
+        const int px = tg.x + static_cast<int>(pix - uly * static_cast<unsigned>(tg.w)), py = tg.y + static_cast<int>(uly);
+        float jx = 0.5f, jy = 0.5f;
+        if (spp_ > 1u) {
+            const float2 j = *reinterpret_cast<const float2*>(draws + (static_cast<size_t>(d.y) * spp_ + sidx) * dd);  // dd is even: 8-byte aligned
+            jx = j.x, jy = j.y;
+        }
+        const C4 c = background(scg, cfg, fd.u(static_cast<float>(px) + jx), fd.v(static_cast<float>(py) + jy));
+        return make_float4(c.r, c.g, c.b, c.a);
+    };
     const uint32_t n_units = ws.counters[kCntUnits];
     const uint32_t spp = cfg.samples_per_pixel > 1 ? static_cast<uint32_t>(cfg.samples_per_pixel) : 1u;
     const float inv_spp = 1.0f / static_cast<float>(spp);
-    const float* fb = view_of(scene_blob).hdr->background;
-    const C4 flat_bg{fb[0], fb[1], fb[2], fb[3]};
     const uint32_t chunk_px = spp <= static_cast<uint32_t>(kBlock) ? static_cast<uint32_t>(kBlock) / spp : 0u;  // pixels per pass (0: a pixel per thread, serially)
     auto put_pixel = [&](const TileGeom& tg, uint32_t i, float4 acc) __attribute__((always_inline)) {
         const uint32_t uly = i / static_cast<uint32_t>(tg.w);
@@ -1581,11 +1604,13 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
         const uint4 d = ws.units[u];
         const TileGeom tg = tile_of(p, static_cast<int>(d.x));
         const uint32_t pp0 = d.y, pp1 = d.z;
+        // the tile's draws: at its touched-tile number, or (all tiles' streams in HBM) at its index in the batch — as in `primary`
+        const float* draws = tile_draws + static_cast<size_t>(p.bg_in_plan ? d.w / ws.tile_slots : static_cast<uint32_t>(static_cast<int>(d.x) - tile_base)) * ws.draws_stride;
         if (chunk_px == 0u) {
             for (uint32_t i = pp0 + threadIdx.x; i < pp1; i += kBlock) {
                 float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 for (uint32_t s = 0; s < spp; ++s) {
-                    const float4 c = sample_colour(ws, d.w + (i - pp0) * spp + s, flat_bg);
+                    const float4 c = unit_sample(d, tg, draws, (i - pp0) * spp + s, spp);
                     acc.x += c.x, acc.y += c.y, acc.z += c.z, acc.w += c.w;
                 }
                 put_pixel(tg, i, acc);
@@ -1594,7 +1619,7 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
         }
         for (uint32_t p0 = pp0; p0 < pp1; p0 += chunk_px) {  // uniform
             const uint32_t npx = min(chunk_px, pp1 - p0);
-            if (threadIdx.x < npx * spp) s_col[threadIdx.x] = sample_colour(ws, d.w + (p0 - pp0) * spp + threadIdx.x, flat_bg);
+            if (threadIdx.x < npx * spp) s_col[threadIdx.x] = unit_sample(d, tg, draws, (p0 - pp0) * spp + threadIdx.x, spp);
             __syncthreads();
             if (threadIdx.x < npx) {
                 float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -2031,7 +2056,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
             launch_levels<kViewHbm>(p, stream, 0);
         }
         const int rgrid = batch_tiles * p.parts_per_tile < resolve_grid ? batch_tiles * p.parts_per_tile : resolve_grid;
-        hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, p.scene, out, out8, p);
+        hipLaunchKernelGGL(resolve_kernel, dim3(rgrid), dim3(kBlock), 0, stream, p.scene, p.ws.tile_draws, out, out8, p, tile_base);
         const int batch = r0 / p.rows_per_batch;
         if (marks && batch < marks->n_batch_done) {
             e = hipEventRecord(marks->batch_done[batch], stream);
