@@ -819,7 +819,10 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
 // ---------------------------------------------------------------------------------------------
 constexpr int kSlabSamples = 16;
 constexpr int kSlabMinSpp = 33;  // `background_kernel` from this many samples per pixel on
-__global__ __launch_bounds__(kBlock) void background_kernel(const uint8_t* __restrict__ scene_blob, const float* __restrict__ tile_draws,
+#ifndef MCRT_BG_WAVES
+#define MCRT_BG_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, MCRT_BG_WAVES) void background_kernel(const uint8_t* __restrict__ scene_blob, const float* __restrict__ tile_draws,
                                                             float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams p,
                                                             const int tile_base, const int n_tiles) {
     __shared__ __align__(16) float2 s_slab[kBlock / 64][64][kSlabSamples + 1];
@@ -857,13 +860,30 @@ __global__ __launch_bounds__(kBlock) void background_kernel(const uint8_t* __res
             const int lx = static_cast<int>(pix - uly * static_cast<unsigned>(tg.w));
             const float fx = static_cast<float>(tg.x + lx), fy = static_cast<float>(tg.y + ly);
             float ar = 0.0f, ag = 0.0f, ab = 0.0f, aa = 0.0f;
+            // A full slab (64 pixels x 16 samples) is fetched into registers one slab AHEAD: lane l takes pair l % 16 of
+            // pixels l / 16, l / 16 + 4, ... — 16 loads, a pixel's 128 bytes across 16 lanes — issued before the previous
+            // slab is consumed, parked in LDS after it: the loads' latency runs under 1 024 background samples.
+            float2 ahead[kSlabSamples];
+            const float2* mine = pairs + static_cast<size_t>(g0 + (static_cast<unsigned>(lane) >> 4)) * spp + (static_cast<unsigned>(lane) & 15u);
+            auto fetch_ahead = [&](unsigned s0) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < kSlabSamples; ++i) ahead[i] = mine[static_cast<size_t>(4 * i) * spp + s0];
+            };
+            const bool full_group = group == 64u;
+            if (full_group && spp >= static_cast<unsigned>(kSlabSamples)) fetch_ahead(0u);
             for (unsigned s0 = 0; s0 < spp; s0 += kSlabSamples) {  // uniform
                 const unsigned ns = min(static_cast<unsigned>(kSlabSamples), spp - s0);
-                const UDiv by_ns(ns);
-                const unsigned items = group * ns;
-                for (unsigned c = static_cast<unsigned>(lane); c < items; c += 64u) {  // neighbouring lanes, neighbouring pairs
-                    const unsigned q = by_ns.div(c), k = c - q * ns;
-                    slab[q][k] = pairs[static_cast<size_t>(g0 + q) * spp + s0 + k];
+                if (full_group && ns == static_cast<unsigned>(kSlabSamples)) {  // uniform
+#pragma unroll
+                    for (int i = 0; i < kSlabSamples; ++i) slab[4 * i + (lane >> 4)][lane & 15] = ahead[i];
+                    if (s0 + 2u * kSlabSamples <= spp) fetch_ahead(s0 + kSlabSamples);  // the next slab is a full one too
+                } else {
+                    const UDiv by_ns(ns);
+                    const unsigned items = group * ns;
+                    for (unsigned c = static_cast<unsigned>(lane); c < items; c += 64u) {  // neighbouring lanes, neighbouring pairs
+                        const unsigned q = by_ns.div(c), k = c - q * ns;
+                        slab[q][k] = pairs[static_cast<size_t>(g0 + q) * spp + s0 + k];
+                    }
                 }
                 wave_sync();
                 if (static_cast<unsigned>(lane) < group) {
