@@ -98,8 +98,9 @@ struct RngKey {
     const void* ptr = nullptr;
     int width = 0, tile_size = 0, first = 0, step = 0, tiles_x = 0, owned_rows = 0;
     int rect[4] = {0, 0, 0, 0};
+    int parts = 0, part_twists = 0;  // the engine states at the starts of the streams' parts depend on these too
     bool operator==(const RngKey& o) const {
-        return ptr == o.ptr && width == o.width && tile_size == o.tile_size && first == o.first && step == o.step && tiles_x == o.tiles_x &&
+        return parts == o.parts && part_twists == o.part_twists && ptr == o.ptr && width == o.width && tile_size == o.tile_size && first == o.first && step == o.step && tiles_x == o.tiles_x &&
                owned_rows == o.owned_rows && rect[0] == o.rect[0] && rect[1] == o.rect[1] && rect[2] == o.rect[2] && rect[3] == o.rect[3];
     }
 };
@@ -455,6 +456,7 @@ RngKey rng_key_of(const RenderParams& p) {
     k.width = p.cfg.width, k.tile_size = p.cfg.tile_size;
     k.first = p.shard.first, k.step = p.shard.step, k.tiles_x = p.shard.tiles_x, k.owned_rows = p.shard.owned_rows;
     k.rect[0] = p.rect_x, k.rect[1] = p.rect_y, k.rect[2] = p.rect_w, k.rect[3] = p.rect_h;
+    k.parts = p.stream_parts, k.part_twists = p.stream_part_twists;
     return k;
 }
 
@@ -587,12 +589,13 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;  // the caller records a graph of its own
     {  // Lanes share the device among themselves; a caller's graph is replayed in circumstances unknown now (no event queries
-       // while it records).  Frames of 2e7 samples and more (three lanes) keep the large grids: their kernels run for
-       // milliseconds, balance counts for more than room for the neighbours (GUI defaults 3.14 / 3.20 ms, 8K 17.9 / 18.0).
+       // while it records).  Frames of 6.4e7 samples and more keep the large grids: their kernels run for milliseconds,
+       // balance counts for more than room for the neighbours (GUI defaults and 4K / 16 spp, 1.3e8 samples: 3.14 / 3.20 ms,
+       // 1.49 / 1.48; 8K 17.9 / 18.0; but 4K / 4 spp, 3.3e7 samples: 0.351 / 0.340 ms).
         const int spp = cfg->samples_per_pixel > 1 ? cfg->samples_per_pixel : 1;
         const double samples = static_cast<double>(whole.owned_rows) * cfg->tile_size * cfg->width * spp;
-        const bool shared = samples < 2.0e7 && (n_lanes > 1 || (!capturing && device_shared(s)));
-        for (int li = 0; li < n_lanes; ++li) choose_grids(p[li], shared);
+        const bool shared = samples < 6.4e7 && (n_lanes > 1 || (!capturing && device_shared(s)));
+        for (int li = 0; li < n_lanes; ++li) choose_grids(p[li], shared, n_lanes);
     }
     if (capturing && groups) return fail(MCRT_ERR_INVALID, "row-group events cannot be recorded into a caller's graph");
     // all renders of a handle share its workspace: they run one after the other whatever streams they are given

@@ -92,9 +92,13 @@ struct RenderParams {
     int layout;            // MCRT_LAYOUT_*
     float* out;            // float4 frame or packed rows (may be NULL when out8 is given)
     uint8_t* out8;         // RGBA8 frame or packed rows, quantised in the epilogue (may be NULL)
-    uint32_t* tile_rng;    // owned_tiles x 624 seeded mt19937 words (NULL when no tile draws)
+    uint32_t* tile_rng;    // owned_tiles x stream_parts x 624 mt19937 state words (NULL when no tile draws)
     WaveSpace ws;
     int draws_per_sample;  // 0, 2 or 4
+    int stream_waves;      // waves per tile in `plan_tiles` (1, 2 or 4, <= stream_parts; choose_grids)
+    int stream_parts;      // a tile's mt19937 stream can be generated in this many parts (1, 2 or 4),
+    int stream_part_twists;  //   of this many 624-word twists each, from engine states kept with the tile seeds (tile_rng:
+                           //   owned_tiles x stream_parts x 624 words)
     int parts_per_tile;    // a tile that meshes can touch is split into this many pixel-aligned work units
     int lds_alpha_words;   // dynamic LDS: alpha-predicate words staged per workgroup
     int lds_face_entries;  // dynamic LDS: n_meshes * 6 face-table entries
@@ -135,8 +139,8 @@ struct WorkspaceBytes {
 };
 // row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
 WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);
-// fills p.shared_device and p.grid_* (MCRT_*_GRID override single grids, development knobs)
-void choose_grids(RenderParams& p, bool shared_device);
+// fills p.shared_device, p.grid_* and p.stream_waves (MCRT_*_GRID / MCRT_STREAM_WAVES override, development knobs)
+void choose_grids(RenderParams& p, bool shared_device, int n_lanes);
 constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
 constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
 constexpr int kCounterWords = 4096;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void seed_tiles_kernel(RenderParams p, int n_ti
     if (tile >= n_tiles) return;
     TileGeom t = tile_of(p, tile);
     uint32_t x = static_cast<uint32_t>(t.y * p.cfg.width + t.x);
-    uint32_t* dst = p.tile_rng + static_cast<size_t>(tile) * 624;
+    uint32_t* dst = p.tile_rng + static_cast<size_t>(tile) * p.stream_parts * 624;
     dst[0] = x;
     for (uint32_t j = 1; j < 624; ++j) {
         x = mt_step(x, j);
@@ -262,14 +262,32 @@ __device__ __forceinline__ void fill_tile(const RenderParams& p, const TileGeom&
 // jitter_only (a background tile under depth of field, 4 draws per sample): only the samples' jitter pairs are stored,
 // packed — sample k's at dst[2k], dst[2k + 1]; no ray leaves a background tile, so its lens draws are never read
 // (tile_renderer.cpp:99-114), and they are half of the stream `primary` would read back.
+//
+// A tile's stream is cut into `stream_parts` PARTS of `stream_part_twists` twists each: the engine's state at the start
+// of every part — after 0, q, 2q, ... twists — is a function of the tile's seed alone and is kept with the tile seeds
+// (advance_tiles_kernel), so `stream_waves` waves (1, 2 or 4, each taking stream_parts / stream_waves consecutive parts)
+// can advance side by side instead of ONE wave running the whole chain of dependent twists (13 at 1080p / 4 spp, 210 at
+// 64 spp: `plan_tiles` alone on the device is the latency of that chain at two waves per SIMD).  A wave writes its own
+// draws, or — background tile — renders the pixels whose FIRST draw lies in its parts; a pixel whose draws run over their
+// end is finished by one more twist of the same wave (the next wave makes the same words again).
 __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint32_t* __restrict__ tile_rng, float* __restrict__ dst,
                                                  float4* __restrict__ out_frame, uchar4* __restrict__ out8, const RenderParams& p,
-                                                 const TileGeom& tg, int tile, uint32_t* st, int lane, bool jitter_only = false) {
+                                                 const TileGeom& tg, int tile, int part, int n_parts, uint32_t* st, int lane, bool jitter_only = false) {
     const int spp = p.cfg.samples_per_pixel > 1 ? p.cfg.samples_per_pixel : 1;
     const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
     const unsigned per_pixel = static_cast<unsigned>(spp) * static_cast<unsigned>(p.draws_per_sample);
     const unsigned total = npix * per_pixel;  // < 2^32 - 2^16 (plan_workspace refuses longer streams): 32-bit index arithmetic throughout
-    const uint32_t* src = tile_rng + static_cast<size_t>(tile) * 624;
+    // this wave: parts [part, part + n_parts) — it starts from the state kept for `part` and simply twists on through the others
+    const unsigned part_draws = static_cast<unsigned>(p.stream_part_twists) * 624u;
+    const unsigned first_draw = static_cast<unsigned>(part) * part_draws;  // (parts x part_draws covers a full tile's stream: no overflow)
+    if (first_draw >= total) return;  // a clipped tile's stream ends before this part
+    const unsigned wave_draws = static_cast<unsigned>(n_parts) * part_draws;
+    const bool last_part = part + n_parts >= p.stream_parts || first_draw + wave_draws >= total;
+    const unsigned end_draw = last_part ? total : first_draw + wave_draws;
+    // background tile: the pixels whose first draw lies in [first_draw, end_draw)
+    const unsigned pix_lo = (first_draw + per_pixel - 1u) / per_pixel;
+    const unsigned pix_hi = last_part ? npix : (end_draw + per_pixel - 1u) / per_pixel;
+    const uint32_t* src = tile_rng + (static_cast<size_t>(tile) * p.stream_parts + part) * 624;
     for (int e = lane; e < 624; e += 64) st[e] = src[e];
     auto wave_sync = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -277,8 +295,8 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
     };
     wave_sync();
     int cur = 0;
-    unsigned pixels_done = 0;
-    for (unsigned done = 0; done < total; done += 624u) {
+    unsigned pixels_done = pix_lo;
+    for (unsigned done = first_draw; dst ? done < end_draw : pixels_done < pix_hi; done += 624u) {  // (a pixel's draws end before `total`)
         const uint32_t* o = st + cur * 624;
         uint32_t* n = st + (cur ^ 1) * 624;
         // mt19937 twist: new[k] from old[k], old[k+1] and old[k+397] (= new[k-227] once k >= 227); the
@@ -322,10 +340,10 @@ __device__ __forceinline__ void tile_stream_wave(const SceneView& sc, const uint
             // go in whole rounds of 64 (a twist completes only 624 / (2 spp) of them — 78 at 4 spp — and a
             // partial round costs as much as a full one); the rest waits for the next twist, except those
             // whose draws reach back into o, which that twist overwrites.
-            const unsigned complete = (done + static_cast<unsigned>(m)) / per_pixel;
+            const unsigned complete = min(pix_hi, (done + static_cast<unsigned>(m)) / per_pixel);
             const unsigned must_end = min(complete, (done + per_pixel - 1u) / per_pixel);  // first draw before `done`
             const unsigned pending = complete - pixels_done;
-            unsigned take = (done + 624u >= total) ? pending : (pending / 64u) * 64u;
+            unsigned take = (complete == pix_hi) ? pending : (pending / 64u) * 64u;
             if (pixels_done + take < must_end) take = must_end - pixels_done;
             if (take > 0u) {
                 // (g and done are even: the pair is 8-byte aligned in either buffer — one LDS read instead of two, half the
@@ -515,14 +533,9 @@ __device__ __forceinline__ void load_point_normal(const WaveSpace& ws, bool pose
 }
 
 // ---------------------------------------------------------------------------------------------
-// plan_tiles: one wave per tile of the batch — which meshes can touch the tile, its units and slot
-// range (plan_tile), then the tile's draws (tile_stream_wave)
+// plan_tiles: 1, 2 or 4 waves per tile of the batch — which meshes can touch the tile (tile_mesh_mask), its units and
+// slot range (plan_touched_tile), then the tile's draws, a part of the stream per wave (tile_stream_wave)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t plan_touched_tile(const RenderParams& p, const TileGeom& tg, int tile, unsigned long long mask);
-struct TilePlan {
-    unsigned long long mask;  // meshes whose screen bound touches the tile (0: a background tile)
-    uint32_t ord;             // the tile's number among the batch's touched tiles (~0u: none)
-};
 // which meshes' screen bounds touch the tile: lane m of the calling wave tests mesh m (pure: no side effects)
 __device__ __forceinline__ unsigned long long tile_mesh_mask(const SceneView& sc, const RenderParams& p, const TileGeom& tg, int lane) {
     const mcrt_config& cfg = p.cfg;
@@ -554,12 +567,6 @@ __device__ __forceinline__ unsigned long long tile_mesh_mask(const SceneView& sc
     unsigned long long mask = __ballot(touch);
     if (!cull && sc.n_meshes > 0) mask = ~0ull;
     return mask;
-}
-__device__ __forceinline__ TilePlan plan_tile(const SceneView& sc, const RenderParams& p, const TileGeom& tg, int tile, int lane) {
-    const unsigned long long mask = tile_mesh_mask(sc, p, tg, lane);
-    uint32_t ord = ~0u;
-    if (lane == 0) ord = plan_touched_tile(p, tg, tile, mask);
-    return TilePlan{mask, static_cast<uint32_t>(__shfl(static_cast<int>(ord), 0))};
 }
 // lane 0 of the tile's wave: units and slot range of a tile that meshes can touch; returns its number
 // among the batch's touched tiles
@@ -596,29 +603,93 @@ __global__ __launch_bounds__(64 * kStreamWaves) void plan_tiles_kernel(const uin
                                                                        uchar4* __restrict__ out8, const RenderParams p,
                                                                        const int tile_base, const int n_tiles) {
     __shared__ __align__(16) uint32_t s_state[kStreamWaves][2 * 624];
+    __shared__ uint32_t s_ord[kStreamWaves];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = static_cast<int>(blockIdx.x) * kStreamWaves + wave;
-    if (t >= n_tiles) return;  // wave-uniform; there is no workgroup barrier in this kernel
-    const int tile = tile_base + t;
+    // `parts` neighbouring waves of the workgroup share a tile (1, 2 or 4: a power of two that divides kStreamWaves), each
+    // taking `per_wave` consecutive parts of the tile's stream
+    const int parts = p.stream_waves;
+    const int per_wave = p.stream_parts / parts;
+    const int slot = static_cast<int>(blockIdx.x) * kStreamWaves + wave;
+    const int t = slot / parts, part = slot - t * parts;
+    const bool valid = t < n_tiles;  // wave-uniform
+    const int tile = tile_base + (valid ? t : 0);
     const TileGeom tg = tile_of(p, tile);
     const SceneView sc = view_of(scene_blob);
-    const TilePlan plan = plan_tile(sc, p, tg, tile, lane);
+    // the tile's mesh mask: every wave of the tile forms it (the same ballot); its slot range and units: the first wave
+    const unsigned long long mask = valid ? tile_mesh_mask(sc, p, tg, lane) : 0ull;
+    if (valid && part == 0 && lane == 0) s_ord[wave] = plan_touched_tile(p, tg, tile, mask);
+    if (parts > 1) {
+        __syncthreads();  // the only workgroup barrier of the kernel: the tile's number among the touched tiles
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!valid) return;
+    const uint32_t ord = s_ord[wave - part];
     const size_t stride = p.ws.draws_stride;
+    const unsigned npix = static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h);
     if (!p.bg_in_plan) {  // every tile's draws to HBM; `primary` renders the background tiles (those of one colour need no draws)
         float4 unused;
-        if (p.draws_per_sample > 0 && !(plan.mask == 0ull && constant_background(sc, p, tg, unused)))
-            tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(t) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane,
-                             /*jitter_only=*/plan.mask == 0ull && p.draws_per_sample == 4);
-    } else if (plan.mask != 0ull) {  // a tile meshes can touch: its draws, at its touched-tile number
-        if (p.draws_per_sample > 0 && plan.ord != ~0u)
-            tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(plan.ord) * stride, nullptr, nullptr, p, tg, tile, s_state[wave], lane);
+        if (p.draws_per_sample > 0 && !(mask == 0ull && constant_background(sc, p, tg, unused)))
+            tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(t) * stride, nullptr, nullptr, p, tg, tile, part * per_wave, per_wave, s_state[wave], lane,
+                             /*jitter_only=*/mask == 0ull && p.draws_per_sample == 4);
+    } else if (mask != 0ull) {  // a tile meshes can touch: its draws, at its touched-tile number
+        if (p.draws_per_sample > 0 && ord != ~0u)
+            tile_stream_wave(sc, tile_rng, tile_draws + static_cast<size_t>(ord) * stride, nullptr, nullptr, p, tg, tile, part * per_wave, per_wave, s_state[wave], lane);
     } else if (float4 pixel; constant_background(sc, p, tg, pixel)) {  // background tile of one colour: no draws, no samples
-        fill_tile(p, tg, out_frame, out8, pixel, static_cast<unsigned>(lane), 64u);
+        fill_tile(p, tg, out_frame, out8, pixel, static_cast<unsigned>(part * 64 + lane), static_cast<unsigned>(parts) * 64u);
     } else if (p.cfg.samples_per_pixel > 1) {  // background tile, jittered samples
-        tile_stream_wave(sc, tile_rng, nullptr, out_frame, out8, p, tg, tile, s_state[wave], lane);
+        tile_stream_wave(sc, tile_rng, nullptr, out_frame, out8, p, tg, tile, part * per_wave, per_wave, s_state[wave], lane);
     } else {  // background tile, one centred sample per pixel: no draws at all
-        background_pixels(sc, p, tg, out_frame, out8, 0u, static_cast<unsigned>(tg.w) * static_cast<unsigned>(tg.h), lane,
+        background_pixels(sc, p, tg, out_frame, out8, npix * static_cast<unsigned>(part) / static_cast<unsigned>(parts),
+                          npix * static_cast<unsigned>(part + 1) / static_cast<unsigned>(parts), lane,
                           [](unsigned, float&, float&) __attribute__((always_inline)) {});
+    }
+}
+
+// The engine states at the starts of a tile's parts 1 .. parts-1 (tile_stream_wave): one wave per tile twists the seeded
+// state part_twists times per part, in LDS, and stores where it stands.  A function of the seeds and of part_twists only:
+// run with the tile seeds, kept across renders with them.
+__global__ __launch_bounds__(64 * kStreamWaves) void advance_tiles_kernel(RenderParams p, int n_tiles) {
+    __shared__ __align__(16) uint32_t s_state[kStreamWaves][2 * 624];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = static_cast<int>(blockIdx.x) * kStreamWaves + wave;
+    if (tile >= n_tiles) return;  // wave-uniform; no workgroup barrier in this kernel
+    uint32_t* st = s_state[wave];
+    uint32_t* states = p.tile_rng + static_cast<size_t>(tile) * p.stream_parts * 624;
+    for (int e = lane; e < 624; e += 64) st[e] = states[e];
+    auto wave_sync = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    wave_sync();
+    int cur = 0;
+    for (int part = 1; part < p.stream_parts; ++part) {
+        for (int k = 0; k < p.stream_part_twists; ++k) {
+            const uint32_t* o = st + cur * 624;
+            uint32_t* n = st + (cur ^ 1) * 624;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = lane + 64 * i;
+                if (e < 227) n[e] = mt_twist(o[e], o[e + 1], o[e + 397]);
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 227 + lane + 64 * i;
+                if (e < 454) n[e] = mt_twist(o[e], o[e + 1], n[e - 227]);
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = 454 + lane + 64 * i;
+                if (e < 624) n[e] = mt_twist(o[e], (e == 623) ? n[0] : o[e + 1], n[e - 227]);
+            }
+            wave_sync();
+            cur ^= 1;
+        }
+        const uint32_t* now = st + cur * 624;
+        for (int e = lane; e < 624; e += 64) states[static_cast<size_t>(part) * 624 + e] = now[e];
     }
 }
 
@@ -1964,7 +2035,20 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     const size_t rec_cap = cap * recs + (p.flat ? static_cast<size_t>(kBlock) * recs : 0);
     p.ws.cap = static_cast<uint32_t>(cap);
     p.ws.tile_cap = static_cast<uint32_t>(cap_tiles);
-    w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 : 0;
+    {  // the tile streams' parts (tile_stream_wave): four waves per tile unless the stream is too short for that
+        static const int parts_knob = [] {  // development knob: MCRT_STREAM_PARTS=1 / 2 / 4
+            const char* e = getenv("MCRT_STREAM_PARTS");
+            const int v = e ? atoi(e) : 0;
+            return (v == 1 || v == 2 || v == 4) ? v : 0;
+        }();
+        const size_t twists = (draws_stride + 623) / 624;  // of a full tile's stream
+        int parts = parts_knob ? parts_knob : kStreamWaves;
+        while (parts > 1 && twists < static_cast<size_t>(2 * parts)) parts >>= 1;  // at least two twists per part
+        p.stream_parts = p.draws_per_sample > 0 ? parts : 1;
+        p.stream_part_twists = static_cast<int>((twists + static_cast<size_t>(p.stream_parts) - 1) / static_cast<size_t>(p.stream_parts));
+        if (p.stream_part_twists < 1) p.stream_part_twists = 1;
+    }
+    w.tile_rng = p.draws_per_sample > 0 ? static_cast<size_t>(n_tiles) * 624 * 4 * static_cast<size_t>(p.stream_parts) : 0;
     w.tile_draws = static_cast<size_t>(rows) * draws_row_bytes + cap_tiles * draws_tile_bytes;
     w.scol = cap * 16;
     w.end = cap * 4;
@@ -1995,12 +2079,22 @@ static int grid_knob(const char* name, int fallback) {
 // cost: 16 per CU balance better than 8, -7 us); frames that share the device — four handles in flight, or the lanes of
 // one large frame — get through fastest with FEWER workgroups per kernel (4 per CU), which leaves CU slots to the other
 // frames' kernels instead of queueing whole kernels behind each other (+4 % frames/s at 1080p; profiles/r03_experiments/grid_sweep*.txt).
-void choose_grids(RenderParams& p, bool shared_device) {
+void choose_grids(RenderParams& p, bool shared_device, int n_lanes) {
     static const int queue_knob = grid_knob("MCRT_QUEUE_GRID", 0);
     static const int primary_knob = grid_knob("MCRT_PRIMARY_GRID", 0),
                      ao_knob = grid_knob("MCRT_AO_GRID", queue_knob), lit_knob = grid_knob("MCRT_LIT_GRID", queue_knob),
                      resolve_knob = grid_knob("MCRT_RESOLVE_GRID", 0);
     p.shared_device = shared_device ? 1 : 0;
+    // `plan_tiles`: a tile's stream by as many waves as it has parts when the chain of twists is what the kernel waits for —
+    // long streams (64 spp: 210-420 twists per tile; GUI defaults alone 4.50 -> 4.10 ms, 8K 18.2 -> 16.8), or a frame alone
+    // on one stream (1080p: -7 us) — and by ONE wave otherwise: four times the waves bring four times the tile set-up, state
+    // loads and partial rounds and take the slots that other frames' or lanes' kernels would fill (-8 % frames/s at 1080p
+    // with four frames in flight, -7 % for 4K / 4 spp on three lanes; profiles/r03_experiments/stream_waves.txt)
+    static const int waves_knob = grid_knob("MCRT_STREAM_WAVES", 0);  // development knob: 1 / 2 / 4
+    const bool long_streams = p.stream_part_twists * p.stream_parts >= 128;
+    p.stream_waves = (long_streams || (!shared_device && n_lanes <= 1)) ? p.stream_parts : 1;
+    if (waves_knob == 1 || waves_knob == 2 || waves_knob == 4) p.stream_waves = waves_knob < p.stream_parts ? waves_knob : p.stream_parts;
+    if (p.stream_waves < 1) p.stream_waves = 1;
     p.grid_primary = primary_knob ? primary_knob : (shared_device ? kSharedGrid : kPrimaryGrid);
     p.grid_ao = ao_knob ? ao_knob : (shared_device ? kSharedGrid : kQueueGrid);
     p.grid_lit = lit_knob ? lit_knob : (shared_device ? kSharedGrid : kLitGridAlone);
@@ -2035,6 +2129,7 @@ hipError_t launch_seed_tiles(const RenderParams& p, hipStream_t stream) {
     const int n = owned_tiles(p);
     if (n <= 0 || p.draws_per_sample <= 0 || !p.tile_rng) return hipSuccess;
     hipLaunchKernelGGL(seed_tiles_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
+    if (p.stream_parts > 1) hipLaunchKernelGGL(advance_tiles_kernel, dim3((n + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream, p, n);
     return hipGetLastError();
 }
 
@@ -2055,7 +2150,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
         // kCounterWords - 1 words were two
         hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 4) * 4, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
+        hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles * (p.stream_waves > 0 ? p.stream_waves : 1) + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
                            p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
         if (marks && marks->after_plan && r0 == 0) {
             e = hipEventRecord(marks->after_plan, stream);
