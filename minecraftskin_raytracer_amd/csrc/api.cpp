@@ -594,8 +594,9 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
        // 1.49 / 1.48; 8K 17.9 / 18.0; but 4K / 4 spp, 3.3e7 samples: 0.351 / 0.340 ms).
         const int spp = cfg->samples_per_pixel > 1 ? cfg->samples_per_pixel : 1;
         const double samples = static_cast<double>(whole.owned_rows) * cfg->tile_size * cfg->width * spp;
-        const bool shared = samples < 6.4e7 && (n_lanes > 1 || (!capturing && device_shared(s)));
-        for (int li = 0; li < n_lanes; ++li) choose_grids(p[li], shared, n_lanes);
+        const bool company = n_lanes > 1 || (!capturing && device_shared(s));
+        const bool shared = company && samples < 6.4e7;
+        for (int li = 0; li < n_lanes; ++li) choose_grids(p[li], shared, company);
     }
     if (capturing && groups) return fail(MCRT_ERR_INVALID, "row-group events cannot be recorded into a caller's graph");
     // all renders of a handle share its workspace: they run one after the other whatever streams they are given

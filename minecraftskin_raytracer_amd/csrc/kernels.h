@@ -140,7 +140,7 @@ struct WorkspaceBytes {
 // row_touched[j]: upper bound of the tiles meshes can touch in owned tile row j (NULL: every tile).
 WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* row_touched);
 // fills p.shared_device, p.grid_* and p.stream_waves (MCRT_*_GRID / MCRT_STREAM_WAVES override, development knobs)
-void choose_grids(RenderParams& p, bool shared_device, int n_lanes);
+void choose_grids(RenderParams& p, bool shared_device, bool company);  // company: other frames or lanes run beside this launch set
 constexpr int kAlphaLdsWordsMax = 4096;  // 64 Ki texels
 constexpr int kFaceLdsEntriesMax = 384;   // 64 meshes
 constexpr int kCounterWords = 4096;

@@ -2079,20 +2079,20 @@ static int grid_knob(const char* name, int fallback) {
 // cost: 16 per CU balance better than 8, -7 us); frames that share the device — four handles in flight, or the lanes of
 // one large frame — get through fastest with FEWER workgroups per kernel (4 per CU), which leaves CU slots to the other
 // frames' kernels instead of queueing whole kernels behind each other (+4 % frames/s at 1080p; profiles/r03_experiments/grid_sweep*.txt).
-void choose_grids(RenderParams& p, bool shared_device, int n_lanes) {
+void choose_grids(RenderParams& p, bool shared_device, bool company) {
     static const int queue_knob = grid_knob("MCRT_QUEUE_GRID", 0);
     static const int primary_knob = grid_knob("MCRT_PRIMARY_GRID", 0),
                      ao_knob = grid_knob("MCRT_AO_GRID", queue_knob), lit_knob = grid_knob("MCRT_LIT_GRID", queue_knob),
                      resolve_knob = grid_knob("MCRT_RESOLVE_GRID", 0);
     p.shared_device = shared_device ? 1 : 0;
     // `plan_tiles`: a tile's stream by as many waves as it has parts when the chain of twists is what the kernel waits for —
-    // long streams (64 spp: 210-420 twists per tile; GUI defaults alone 4.50 -> 4.10 ms, 8K 18.2 -> 16.8), or a frame alone
-    // on one stream (1080p: -7 us) — and by ONE wave otherwise: four times the waves bring four times the tile set-up, state
+    // long streams (64 spp: 210-420 twists per tile; GUI defaults alone 4.50 -> 4.10 ms, 8K 18.2 -> 16.8), or a frame that has
+    // no company at all, neither other frames nor lanes of its own (1080p: -7 us) — and by ONE wave otherwise: four times the waves bring four times the tile set-up, state
     // loads and partial rounds and take the slots that other frames' or lanes' kernels would fill (-8 % frames/s at 1080p
     // with four frames in flight, -7 % for 4K / 4 spp on three lanes; profiles/r03_experiments/stream_waves.txt)
     static const int waves_knob = grid_knob("MCRT_STREAM_WAVES", 0);  // development knob: 1 / 2 / 4
     const bool long_streams = p.stream_part_twists * p.stream_parts >= 128;
-    p.stream_waves = (long_streams || (!shared_device && n_lanes <= 1)) ? p.stream_parts : 1;
+    p.stream_waves = (long_streams || !company) ? p.stream_parts : 1;
     if (waves_knob == 1 || waves_knob == 2 || waves_knob == 4) p.stream_waves = waves_knob < p.stream_parts ? waves_knob : p.stream_parts;
     if (p.stream_waves < 1) p.stream_waves = 1;
     p.grid_primary = primary_knob ? primary_knob : (shared_device ? kSharedGrid : kPrimaryGrid);

@@ -17,6 +17,11 @@ MCRT_LANES=1 PMC_SETS=$SETS $R/tools/pmc_run.sh gpurun_out/$TAG/pmc tools/gpu_ca
 python3 $R/tools/pmc_frame.py $O/pmc_dispatches_1lane.txt > $O/pmc_frame.txt 2>&1
 python3 $R/tools/pmc_update.py 1080p_b4_spp4_S64 $O/pmc_dispatches_1lane.txt profiles/$TAG >> $O/pmc_update.log 2>&1
 cp $O/pmc/summary.txt $O/pmc_summary_1lane.txt 2>/dev/null
+# the metric frame once more in the launch shapes of a frame that shares the device (what `value` runs): the pipelined figures
+MCRT_SHARED_GRIDS=1 MCRT_LANES=1 PMC_SETS=core $R/tools/pmc_run.sh gpurun_out/$TAG/pmc_shared tools/gpu_case.py base 1 > $O/pmc_dispatches_1lane_shared.txt 2>&1
+python3 $R/tools/pmc_frame.py $O/pmc_dispatches_1lane_shared.txt > $O/pmc_frame_shared.txt 2>&1
+python3 $R/tools/pmc_update.py 1080p_b4_spp4_S64 $O/pmc_dispatches_1lane_shared.txt profiles/$TAG pipelined >> $O/pmc_update.log 2>&1
+rm -rf $O/pmc_shared/pass*
 for PAIR in gui_defaults:gui 4k_b4_spp4_S64:4k_b4 4k_b8_spp16_S64:4k 8k_b8_spp64_S32:8k 256_b1_spp1_S64:c256; do
   W=${PAIR%%:*}; C=${PAIR##*:}
   MCRT_LANES=1 PMC_SETS=core $R/tools/pmc_run.sh gpurun_out/$TAG/pmc_$C tools/gpu_case.py $C 1 > $O/pmc_dispatches_$C.txt 2>&1

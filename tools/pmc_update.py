@@ -2,13 +2,16 @@
     python tools/pmc_update.py <workload> <dispatches.txt> <profile tag>
 Per frame (the last complete one of the run): HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (rocprofv3 counts KiB; FETCH doubled
 per the gfx950 correction of MI355X_MICROARCH.md), VALU wave-instructions = SQ_INSTS_VALU, both summed over the frame's dispatches,
-plus the per-kernel split and the hash of the kernel sources the run was taken on (bench.py flags counters of other sources as stale)."""
+plus the per-kernel split and the hash of the kernel sources the run was taken on (bench.py flags counters of other sources as stale).
+A 4th argument stores the counters as a named sub-entry instead ("pipelined": the run was taken with MCRT_SHARED_GRIDS=1, the launch
+shapes of a frame that shares the device — what bench.py's `value` runs)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
 workload, path, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+variant = sys.argv[4] if len(sys.argv) > 4 else None  # "pipelined": counters of the launch shapes a frame takes when frames share the device
 rows, hdr = [], None
 for l in open(path).read().splitlines():
     if l.startswith('idx kernel'):
@@ -40,6 +43,10 @@ for k in ("before_bundle_decisions", "without_seed_table"):  # round 2's named p
         history[old[k].get("profile", k)] = {x: old[k][x] for x in ("hbm_bytes", "valu_wave_instructions")}
 if history:
     entry["history"] = history
+if variant:  # a sub-entry of the workload's entry (which must exist: run the plain pass first)
+    sub = {k: entry[k] for k in ("hbm_bytes", "valu_wave_instructions", "source_hash", "per_kernel")}
+    old[variant] = sub
+    entry = old
 data[workload] = entry
 json.dump(data, open(out, "w"), indent=1)
 print(json.dumps({workload: {k: entry[k] for k in ("hbm_bytes", "valu_wave_instructions", "source_hash")}}))
