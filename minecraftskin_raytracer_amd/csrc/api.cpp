@@ -801,14 +801,17 @@ void free_unused_seed_tables() {  // mcrt_trim
 
 // keeps `s` for reuse unless it is large — MCRT_POOL_MB, by default a twelfth of the device's memory (24 GB of the
 // MI355X's 288: the 1080p and 4K frames of BASELINE.json stay pooled, and a host application that never calls
-// mcrt_trim() does not sit on a fifth of the card; re-allocating the tens of GB an 8K / 64 spp frame needs costs each
-// one-shot call of such a frame about a second) — or the device already has one
-bool pool_scene(mcrt_scene* s) {
+// mcrt_trim() does not sit on a fifth of the card; the one-shot entry points plan their workspace to stay below it, see
+// render_to_host) — or the device already has one
+size_t pool_limit(int device) {
     static const long long forced_mb = [] {
         const char* e = std::getenv("MCRT_POOL_MB");
         return e ? std::atoll(e) : -1ll;
     }();
-    const size_t limit = forced_mb >= 0 ? static_cast<size_t>(forced_mb) << 20 : device_total_memory(s->device) / 12;
+    return forced_mb >= 0 ? static_cast<size_t>(forced_mb) << 20 : device_total_memory(device) / 12;
+}
+bool pool_scene(mcrt_scene* s) {
+    const size_t limit = pool_limit(s->device);
     if (workspace_bytes(s) > limit) return false;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (mcrt_scene* q : g_pool)
@@ -1227,6 +1230,18 @@ int render_to_host(const mcrt_scene_desc* desc, const mcrt_config* cfg, void* ou
         if (e != hipSuccess) {
             rc = hip_fail(e, "frame allocation");
             break;
+        }
+        {   // A one-shot render plans its workspace to stay poolable: with the default budget (a third of the device) an
+            // 8K / 64 spp frame would take tens of GB that no pool keeps — allocated and freed on EVERY call, and a hipMalloc
+            // of that size now and then stalls for seconds (3.6-4.5 s observed, tools/gpu_hostpath_8k.py).  Below the pool's
+            // limit the frame is cut into a few more passes (8K: +2 % device time) and the next call finds its buffers.
+            const size_t limit = pool_limit(s->device);
+            const size_t fixed = s->blob.bytes + s->frame.bytes + (static_cast<size_t>(512) << 20);  // + tile states, tables' slack
+            if (limit > 2 * fixed) {
+                const size_t room = (limit - fixed) / 10 * 9;
+                const size_t budget = workspace_budget(s->device);
+                s->budget = budget < room ? budget : room;
+            }
         }
         if (r == 0) (void)hipEventRecord(s->ev[0], s->main_stream);
         rc = enqueue_render(s, cfg, r, n_ranks, packed ? MCRT_LAYOUT_PACKED : MCRT_LAYOUT_FRAME, px_bytes == 16 ? static_cast<float*>(s->frame.ptr) : nullptr,
