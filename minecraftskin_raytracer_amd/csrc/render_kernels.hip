@@ -71,7 +71,7 @@ constexpr int kPrimaryGrid = MCRT_PRIMARY_GRID; // persistent primary workgroups
 constexpr int kQueueGrid = 2048;   // workgroups of the queue kernels (grid-stride over device-side counts)
 constexpr int kLitGridAlone = 4096;  // `lit` of a frame that has the device to itself
 constexpr int kResolveGrid = 4096;
-constexpr int kSharedGrid = 1024;  // every kernel of a frame that shares the device (choose_grids)
+constexpr int kSharedGrid = 896;   // every kernel of a frame that shares the device (choose_grids): 3.5 workgroups per CU
 
 // n / d for a divisor that is the same for the whole wave: a shift when it is a power of two (tile widths of 32,
 // 4 samples per pixel: the usual case) instead of the ~25-instruction expansion of a 32-bit division.
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
                 hit = hit_scene(sc, ray, mesh_mask);
                 // A miss: its colour is a function of the sample's jitter pair alone (tile_renderer.cpp:111-114) — `resolve`
                 // forms it from the pair in the tile's stream (8 B) instead of a colour stored here and read back there
-                // (2 x 16 B for each of the 1.35 M misses of the metric frame's touched tiles: 43 MB of its HBM traffic).
+                // (2 x 16 B per miss of a touched tile: 13 MB of the metric frame's counted HBM traffic).
                 uint32_t code = kEndMiss;
                 if (hit.hit && cfg.max_bounces < 0) {
                     const C4 col = background(sc, cfg, 0.5f, 0.5f);  // raytracer.cpp:86-90 (depth 0 > maxBounces)
