@@ -500,7 +500,7 @@ def main() -> None:
             "latency_ms": round(latency_ms, 4),
             "latency_mpixels_per_s": round(w * h / latency_ms / 1e3, 2),
             "kernel": {"pipeline_ms": round(pipeline_ms, 4),
-                       "note": "hipEvents on the launch stream around one frame's whole pipeline on one stream (counter memset, plan_tiles, "
+                       "note": "hipEvents on the launch stream around one frame's whole pipeline on one stream (plan_tiles, "
                                "primary, [ao,] lit, resolve)"},
             "roofline": roof,
         }

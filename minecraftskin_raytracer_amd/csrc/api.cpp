@@ -110,6 +110,7 @@ struct Lane {
     // wavefront workspace, grown on demand (never shrinks; no allocation in the steady state)
     DeviceBuffer tile_rng, tile_draws, scol, end, units, unit_hits, tile_mask, queues[5], texel_refs, targets, cand, lit[2], stack, counters, hit_rng;
     RngKey rng_key;               // which tile seeds tile_rng holds (ptr == nullptr: none)
+    bool counters_dirty = false;  // a render's launches failed half way: counters and their base no longer fit (cleared before the next render)
 };
 
 struct mcrt_scene {
@@ -394,6 +395,8 @@ int prepare(mcrt_scene* sc, int li, int n_lanes, const mcrt_config* cfg, int fir
     ws.unit_hits = static_cast<uint32_t*>(s->unit_hits.ptr);
     ws.stack = static_cast<float4*>(s->stack.ptr);
     ws.counters = static_cast<uint32_t*>(s->counters.ptr);
+    ws.counter_base = ws.counters + kCounterWords;
+    ws.frame_info = ws.counters + 2 * kCounterWords;
     ws.hit_rng = w.hit_rng ? static_cast<uint32_t*>(s->hit_rng.ptr) : nullptr;
     return MCRT_OK;
 }
@@ -460,7 +463,7 @@ RngKey rng_key_of(const RenderParams& p) {
     return k;
 }
 
-// MCRT_GRAPH=0 turns launch recording off (every render then issues its 7 launches per lane and pass itself)
+// MCRT_GRAPH=0 turns launch recording off (every render then issues its four launches per lane and pass itself)
 bool graphs_enabled() {
     static const bool v = [] {
         const char* e = std::getenv("MCRT_GRAPH");
@@ -616,6 +619,19 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
         HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
         s->busy_probe.store(s->last_done, std::memory_order_release);
     }
+    // The pass counters run on from render to render (`resolve` leaves their values as the next pass's base): no memset per
+    // pass.  Only after a render whose launches failed half way are they put back to zero, base and all but the sticky flags.
+    for (int li = 0; li < n_lanes; ++li) {
+        Lane& ln = s->lanes[li];
+        if (!ln.counters_dirty || !ln.counters.ptr) continue;
+        uint32_t* c = static_cast<uint32_t*>(ln.counters.ptr);
+        HIP_TRY(hipMemsetAsync(c, 0, static_cast<size_t>(kCounterWords - 4) * 4, stream));
+        HIP_TRY(hipMemsetAsync(c + kCounterWords, 0, (static_cast<size_t>(kCounterWords) + 4) * 4, stream));
+        ln.counters_dirty = false;
+    }
+    auto launches_failed = [&]() {
+        for (int li = 0; li < n_lanes; ++li) s->lanes[li].counters_dirty = true;
+    };
     int rc;
     if (groups) {
         // which rows are final when: a row that holds no touched tile is complete behind plan_tiles (which
@@ -656,6 +672,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
             }
         }
         rc = launch_lanes(s, p, n_lanes, stream, marks);
+        if (rc != MCRT_OK) launches_failed();
         if (rc == MCRT_OK) {
             HIP_TRY(hipEventRecord(s->last_done, stream));
             late.wait.push_back(s->last_done);
@@ -668,6 +685,7 @@ int enqueue_render(mcrt_scene* s, const mcrt_config* cfg, int first, int step, i
         return rc;
     }
     rc = capturing ? launch_lanes(s, p, n_lanes, stream) : launch_or_replay(s, p, n_lanes, stream, may_record);
+    if (rc != MCRT_OK) launches_failed();
     if (rc == MCRT_OK && !capturing) {
         HIP_TRY(hipEventRecord(s->last_done, stream));
         s->last_stream = stream;

@@ -61,9 +61,11 @@ struct WaveSpace {
                             // hits (general variants: ping-pong by level parity, [cap] each)
     float4* stack;          // [stack_stride][cap] level colours of the chains, plane-major: depth d of the chain of sample slot r
                             // at [d * cap + r] — the level-0 colours of neighbouring samples share cache lines
+    uint32_t* counter_base; // the counters' values when the pass began (the previous pass's `resolve` left them): a pass's counts are differences
+    uint32_t* frame_info;   // [0] units of the pass, left by `primary` for `resolve`
     uint32_t* counters;     // [0] units in `units`, [1] touched tiles, [8 + L] entries of level L >= 1
                             // ([9] = level-1 records), [last] touched-tile bound exceeded (never, by construction; sticky);
-                            // cleared per pass but for the last
+                            // never cleared: running counts (modulo 2^32) against counter_base
     uint32_t* hit_rng;      // general variants: per-thread 624-word mt19937 states (long streams)
     uint32_t cap;           // slot capacity (= samples of the touched tiles of the largest batch)
     uint32_t tile_slots;    // slots per touched tile: min(tile, width) * min(tile, height) * spp

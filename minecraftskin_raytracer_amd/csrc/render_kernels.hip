@@ -451,7 +451,14 @@ __device__ __forceinline__ uint32_t chain_code(int records, bool stopped_at_max)
 constexpr int kCntUnits = 0;
 constexpr int kCntTiles = 1;     // touched tiles of the batch so far
 constexpr int kCntOverflow = kCounterWords - 1;  // set if more tiles are touched than the host planned for (a bug: the host
-                                                 // bound is a superset); the per-batch memset leaves this word alone
+                                                 // bound is a superset); sticky
+
+// The pass counters are never cleared: they run on from pass to pass (modulo 2^32), and what a pass has counted is the
+// difference to `counter_base`, the snapshot `resolve` — the last kernel of every pass, in which nothing counts any more —
+// takes for the pass that follows.  (A memset per pass was a dispatch of its own at the head of every frame: 3 us and a
+// launch of a lone frame's 195.)  `resolve` itself reads the one count it needs from frame_info, which `primary` leaves.
+__device__ __forceinline__ uint32_t counted(const WaveSpace& ws, int i) { return ws.counters[i] - ws.counter_base[i]; }
+__device__ __forceinline__ uint32_t count_add(const WaveSpace& ws, int i, uint32_t n) { return atomicAdd(&ws.counters[i], n) - ws.counter_base[i]; }
 
 // Rank of this thread's item among the workgroup's flagged items, and their total: ballot per wave,
 // four wave counts through LDS.  Collective (two barriers: the counts are reusable right after).
@@ -582,13 +589,13 @@ __device__ __forceinline__ uint32_t plan_touched_tile(const RenderParams& p, con
     const uint32_t used = (npix + per - 1u) / per;
     // the k-th touched tile of the batch owns slot range k: the workspace is sized for the tiles that can
     // be touched (host-side superset), not for every sample of the batch
-    const uint32_t ord = atomicAdd(&ws.counters[kCntTiles], 1u);
+    const uint32_t ord = count_add(ws, kCntTiles, 1u);
     if (ord >= ws.tile_cap) {  // cannot happen; keep memory safe and leave a mark if it ever does
         ws.counters[kCntOverflow] = 1u;
         ws.tile_mask[tile] = 0ull;
         return ~0u;
     }
-    const uint32_t slot0 = atomicAdd(&ws.counters[kCntUnits], used);
+    const uint32_t slot0 = count_add(ws, kCntUnits, used);
     const uint32_t base = ord * ws.tile_slots;
     for (uint32_t i = 0; i < used; ++i) {
         const uint32_t a = i * per, b = min(npix, a + per);
@@ -715,7 +722,8 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
     const SceneView scg = view_of(scene_blob);
     const mcrt_config& cfg = p.cfg;
     const WaveSpace& ws = p.ws;
-    const uint32_t n_units = ws.counters[kCntUnits];
+    const uint32_t n_units = counted(ws, kCntUnits);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws.frame_info[0] = n_units;  // for `resolve`, which takes the next pass's counter base
     if ((p.bg_in_plan || p.bg_kernel) && blockIdx.x >= n_units) return;  // nothing for this workgroup: leave before the collective staging
     // flat pipeline: the reflection ray of every primary hit (raytracer.cpp:133-139) is traced right here, by the first
     // `total` threads of the block on the chunk's packed hits (as a launch of its own this stage re-read every record:
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(kBlock, MCRT_PRIMARY_WAVES) void primary_kernel(con
                 int survivors = 0;
                 const int srank = block_rank(next_hit, s_wcnt, survivors);
                 if (survivors > 0) {  // uniform
-                    if (tid == 0) s_out_base = atomicAdd(&ws.counters[kCntDeep1], static_cast<uint32_t>(survivors));
+                    if (tid == 0) s_out_base = count_add(ws, kCntDeep1, static_cast<uint32_t>(survivors));
                     __syncthreads();
                     if (next_hit) push_record(ws, posed, ws.cap + s_out_base + static_cast<uint32_t>(srank), nray, nhit, root, 1, true);
                 }
@@ -1003,7 +1011,7 @@ struct Scope {
     __device__ __forceinline__ int par() const { return flat ? 0 : (level & 1); }
 };
 __device__ __forceinline__ uint32_t dense_count(const WaveSpace& ws, Scope s) {
-    return s.flat ? ws.counters[kCntDeep1] : ws.counters[kCntDense + s.level];  // (flat: the level-1 records; deeper ones are private to `lit`'s chasing blocks)
+    return s.flat ? counted(ws, kCntDeep1) : counted(ws, kCntDense + s.level);  // (flat: the level-1 records; deeper ones are private to `lit`'s chasing blocks)
 }
 __device__ __forceinline__ uint32_t dense_base(const WaveSpace& ws, Scope s) { return s.flat ? ws.cap : 0u; }
 
@@ -1011,7 +1019,7 @@ __device__ __forceinline__ uint32_t dense_base(const WaveSpace& ws, Scope s) { r
 // every thread of the workgroup makes the same calls (collectives inside the body are allowed).
 template <class F>
 __device__ __forceinline__ void for_each_unit_block(const WaveSpace& ws, F&& body) {
-    const uint32_t n_units = ws.counters[kCntUnits];
+    const uint32_t n_units = counted(ws, kCntUnits);
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint32_t base = ws.units[u].w;
         const uint32_t count = ws.unit_hits[u];
@@ -1030,7 +1038,7 @@ __device__ __forceinline__ void for_each_entry_block(const WaveSpace& ws, Scope 
 // True when this workgroup will get no entry block of the scope: it can leave before it stages the scene
 // tables (a deep level holds a few thousand entries, yet every workgroup of a launch would stage 8.7 KB).
 __device__ __forceinline__ bool no_entry_blocks(const WaveSpace& ws, Scope s) {
-    if (s.units() && blockIdx.x < ws.counters[kCntUnits]) return false;
+    if (s.units() && blockIdx.x < counted(ws, kCntUnits)) return false;
     if (s.dense() && static_cast<unsigned long long>(blockIdx.x) * kBlock < dense_count(ws, s)) return false;
     return true;
 }
@@ -1149,7 +1157,7 @@ __global__ __launch_bounds__(kBlock, MCRT_SHADOW_WAVES) void shadow_kernel(const
     const bool pow2 = (pairs_per_hit & (pairs_per_hit - 1u)) == 0u && pairs_per_hit <= 64u;
     const uint32_t n_dense = scope.dense() ? dense_count(ws, scope) : 0u;
     {  // leave before the collective staging when this workgroup gets nothing
-        const bool some_units = scope.units() && blockIdx.x < ws.counters[kCntUnits];
+        const bool some_units = scope.units() && blockIdx.x < counted(ws, kCntUnits);
         const unsigned long long dense_items = pow2 ? static_cast<unsigned long long>(n_dense) * pairs_per_hit : n_dense;  // pow2: strided over pairs
         if (!some_units && static_cast<unsigned long long>(blockIdx.x) * kBlock >= dense_items) return;
     }
@@ -1243,7 +1251,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     const Scope scope{0, 1};
     // ONE work list — the units' record ranges, then the dense queue in blocks of 256 — so that the three phases
     // exist once in the code object (inlined per list they made 33 KB, half the instruction cache)
-    const uint32_t n_units = ws.counters[kCntUnits];
+    const uint32_t n_units = counted(ws, kCntUnits);
     const uint32_t n_dense = dense_count(ws, scope);
     const uint32_t n_items = n_units + (n_dense + kBlock - 1u) / kBlock;
     // The chase: the chains below the level-1 records are followed HERE, ahead of the work list — a block of 256
@@ -1253,7 +1261,7 @@ __global__ __launch_bounds__(kBlock, MCRT_LIT_WAVES) void lit_kernel(const uint8
     // (As a launch of its own between `primary` and `lit` the chase was 32 us of a lone frame's 225 for 2 us of work —
     // three dependent scene queries on 122 workgroups; in here it costs `lit` 5.)
     const int max_b = p.cfg.max_bounces;
-    const uint32_t count1 = ws.counters[kCntDeep1];
+    const uint32_t count1 = counted(ws, kCntDeep1);
     const uint32_t n_chase = max_b >= 1 ? (count1 + kBlock - 1u) / kBlock : 0u;
     const uint32_t n_work = n_chase + n_items;
     if (blockIdx.x >= n_work) return;  // before the collective staging
@@ -1481,7 +1489,7 @@ __global__ __launch_bounds__(kBlock, MCRT_AO_WAVES) void ao_kernel(const uint8_t
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const SceneView scg = view_of(scene_blob);
     const WaveSpace& ws = p.ws;
-    if (blockIdx.x >= ws.counters[kCntUnits]) return;
+    if (blockIdx.x >= counted(ws, kCntUnits)) return;
     const typename ViewSel<kView>::type sc = ViewSel<kView>::make(scg, p, s_dyn);
     constexpr bool kPosed = kView != kViewLdsUnposed;
     const bool posed = kPosed && p.scene_posed != 0;
@@ -1607,7 +1615,7 @@ __global__ __launch_bounds__(kBlock, 2) void level_shade_kernel(const uint8_t* _
         int total = 0;
         const int rank = block_rank(next_hit, s_wcnt, total);
         if (total > 0) {  // uniform
-            if (threadIdx.x == 0) s_out_base = atomicAdd(&ws.counters[kCntDense + level + 1], static_cast<uint32_t>(total));
+            if (threadIdx.x == 0) s_out_base = count_add(ws, kCntDense + level + 1, static_cast<uint32_t>(total));
             const bool soft = mode == SHADOW_SOFT;
             if (next_hit && soft) {  // hand the new hit to thread `rank`: the survivors' work below runs packed
                 s_np[rank] = make_float4(nhit.p.x, nhit.p.y, nhit.p.z, __int_as_float(depth + 1));
@@ -1678,7 +1686,7 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
         const C4 c = background(scg, cfg, fd.u(static_cast<float>(px) + jx), fd.v(static_cast<float>(py) + jy));
         return make_float4(c.r, c.g, c.b, c.a);
     };
-    const uint32_t n_units = ws.counters[kCntUnits];
+    const uint32_t n_units = ws.frame_info[0];  // (not from the counters: this kernel moves their base)
     const uint32_t spp = cfg.samples_per_pixel > 1 ? static_cast<uint32_t>(cfg.samples_per_pixel) : 1u;
     const float inv_spp = 1.0f / static_cast<float>(spp);
     const uint32_t chunk_px = spp <= static_cast<uint32_t>(kBlock) ? static_cast<uint32_t>(kBlock) / spp : 0u;  // pixels per pass (0: a pixel per thread, serially)
@@ -1691,6 +1699,9 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const uint8_t* __restri
                     make_float4(acc.x * inv_spp, acc.y * inv_spp, acc.z * inv_spp, acc.w * inv_spp));
     };
     MCRT_HOOK_RESOLVE_BEGIN()
+    if (blockIdx.x == 0) {  // the pass has counted everything: where the counters stand is the next pass's base
+        for (int i = threadIdx.x; i < kCounterWords - 4; i += kBlock) ws.counter_base[i] = ws.counters[i];
+    }
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint4 d = ws.units[u];
         const TileGeom tg = tile_of(p, static_cast<int>(d.x));
@@ -2063,7 +2074,7 @@ WorkspaceBytes plan_workspace(RenderParams& p, size_t budget_bytes, const int* r
     w.lit0 = p.flat ? 4 : cap * 4;  // the flat pipeline keeps the lit counts in LDS
     w.lit1 = cap * 4;
     w.stack = cap * 16 * static_cast<size_t>(p.ws.stack_stride);
-    w.counters = static_cast<size_t>(kCounterWords) * 4;
+    w.counters = (static_cast<size_t>(kCounterWords) * 2 + 4) * 4;  // the counters, their base (the previous pass's last values), frame_info
     w.hit_rng = p.flat ? 0 : static_cast<size_t>(256) * kBlock * 624 * 4;  // general grids are capped at 256 WGs
     return w;
 }
@@ -2144,12 +2155,7 @@ hipError_t launch_render(const RenderParams& p, hipStream_t stream, const Launch
         const int rows = p.rows_per_batch < p.shard.owned_rows - r0 ? p.rows_per_batch : p.shard.owned_rows - r0;
         const int tile_base = r0 * p.shard.tiles_x;
         const int batch_tiles = rows * p.shard.tiles_x;
-        // (Clearing the counters from the pass's last kernel instead — the last workgroup of `resolve` to finish —
-        // was tried: its 4096 returning atomics on one ticket word took 85 us, the ~88 ops/us of one address.)
-        // all but the last four words (the sticky overflow word among them): a 16-byte multiple is ONE fill kernel,
-        // kCounterWords - 1 words were two
-        hipError_t e = hipMemsetAsync(p.ws.counters, 0, static_cast<size_t>(kCounterWords - 4) * 4, stream);
-        if (e != hipSuccess) return e;
+        hipError_t e = hipSuccess;  // (no counter memset: the counters run on, `resolve` moves their base)
         hipLaunchKernelGGL(plan_tiles_kernel, dim3((batch_tiles * (p.stream_waves > 0 ? p.stream_waves : 1) + kStreamWaves - 1) / kStreamWaves), dim3(64 * kStreamWaves), 0, stream,
                            p.scene, p.tile_rng, p.ws.tile_draws, out, out8, p, tile_base, batch_tiles);
         if (marks && marks->after_plan && r0 == 0) {

@@ -31,8 +31,12 @@
 
 // resolve_kernel: the pass's summary line (tools/decide_check.sh sums them)
 #define MCRT_HOOK_RESOLVE_BEGIN()                                                                                                        \
-    if (blockIdx.x == 0 && threadIdx.x == 0)                                                                                            \
-        printf("DECIDE_CHECK records: %u undecided, %u decided all-shadowed, %u decided all-lit, %u CONTRADICTED\n", ws.counters[2000],   \
-               ws.counters[2001], ws.counters[2002], ws.counters[2003]);
+    if (blockIdx.x == 0) { /* before this block moves the counters' base */                                                             \
+        if (threadIdx.x == 0)                                                                                                           \
+            printf("DECIDE_CHECK records: %u undecided, %u decided all-shadowed, %u decided all-lit, %u CONTRADICTED\n",                 \
+                   ws.counters[2000] - ws.counter_base[2000], ws.counters[2001] - ws.counter_base[2001],                                \
+                   ws.counters[2002] - ws.counter_base[2002], ws.counters[2003] - ws.counter_base[2003]);                               \
+        __syncthreads();                                                                                                                \
+    }
 
 #endif

@@ -11,11 +11,12 @@ for l in open(sys.argv[1]).read().splitlines():
         parts = l.split()
         n = len(hdr)
         rows.append((' '.join(parts[1:-n]), dict(zip(hdr, map(float, parts[-n:])))))
-# the last COMPLETE frame: from the fill kernel ahead of a plan_tiles to the resolve that follows it
+# the last COMPLETE frame: from a plan_tiles to the resolve that follows it
 ends = [i for i, (n, d) in enumerate(rows) if 'resolve' in n]
 end = ends[-1]
 start = max(i for i, (n, d) in enumerate(rows[:end]) if 'plan_tiles' in n)
-frame = rows[max(0, start - 1):end + 1]
+first = start - 1 if start > 0 and 'fillBuffer' in rows[start - 1][0] else start  # (older builds cleared the counters ahead of plan_tiles)
+frame = rows[first:end + 1]
 tf = tw = tv = 0.0
 for n, d in frame:
     f, w, v = d.get('FETCH_SIZE', 0), d.get('WRITE_SIZE', 0), d.get('SQ_INSTS_VALU', 0)

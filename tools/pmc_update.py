@@ -23,7 +23,8 @@ for l in open(path).read().splitlines():
 ends = [i for i, (n, d) in enumerate(rows) if 'resolve' in n]
 end = ends[-1]
 start = max(i for i, (n, d) in enumerate(rows[:end]) if 'plan_tiles' in n)
-frame = rows[max(0, start - 1):end + 1]
+first = start - 1 if start > 0 and 'fillBuffer' in rows[start - 1][0] else start  # (older builds cleared the counters ahead of plan_tiles)
+frame = rows[first:end + 1]
 per_kernel, tf, tw, tv = {}, 0.0, 0.0, 0.0
 for n, d in frame:
     f, w, v = d.get('FETCH_SIZE', 0.0), d.get('WRITE_SIZE', 0.0), d.get('SQ_INSTS_VALU', 0.0)
