@@ -210,7 +210,12 @@ int lane_count(const mcrt_scene* s, const mcrt_config& cfg, const Shard& sh) {
     } else {
         const int spp = cfg.samples_per_pixel > 1 ? cfg.samples_per_pixel : 1;
         const double samples = static_cast<double>(sh.owned_rows) * cfg.tile_size * cfg.width * spp;
-        lanes = samples >= 2.0e7 ? 3 : (samples >= 4.0e6 ? 2 : 1);  // (3840x2160 / 4 spp alone: 0.54 / 0.485 / 0.465 ms with 1 / 2 / 3 lanes)
+        // One lane up to 2.8e7 samples, three above.  With the launch shapes of a frame that is alone on ONE stream (four
+        // waves per tile stream, `lit` at 4 096 workgroups: choose_grids) a single lane beats two or three for every frame
+        // up to 2560x1440 / 6 spp (1080p / 4 spp alone: 0.189 / 0.224 / 0.215 ms with 1 / 2 / 3 lanes; 1440p / 6 spp: 0.416 /
+        // 0.439 / 0.423); 3840x2160 / 4 spp, 3.3e7 samples: 0.515 / 0.511 / 0.496, and the gap widens from there (GUI defaults,
+        // 1.3e8: 5.07 / 4.30 / 4.13).  Two lanes never came out first.
+        lanes = samples >= 2.8e7 ? 3 : 1;
     }
     lanes = std::min(lanes, kMaxLanes);
     return std::max(1, std::min(lanes, sh.owned_rows));

@@ -22,6 +22,10 @@ CASES = {
     "8k": (lambda: scenes.skin_scene("S32", 0), dict(width=7680, height=4320, maxBounces=8, samplesPerPixel=64)),
     "4k": (lambda: scenes.skin_scene("S64", 0), dict(width=3840, height=2160, maxBounces=8, samplesPerPixel=16)),
     "4k_b4": (lambda: scenes.skin_scene("S64", 0), dict(width=3840, height=2160, maxBounces=4, samplesPerPixel=4)),
+    "1080p_spp8": (lambda: scenes.skin_scene("S64", 0), dict(width=1920, height=1080, maxBounces=4, samplesPerPixel=8)),
+    "1440p": (lambda: scenes.skin_scene("S64", 0), dict(width=2560, height=1440, maxBounces=4, samplesPerPixel=4)),
+    "1440p_spp6": (lambda: scenes.skin_scene("S64", 0), dict(width=2560, height=1440, maxBounces=4, samplesPerPixel=6)),
+    "720p": (lambda: scenes.skin_scene("S64", 0), dict(width=1280, height=720, maxBounces=4, samplesPerPixel=4)),
     "c256": (lambda: scenes.skin_scene("S64", 0), dict(width=256, height=256, maxBounces=1, samplesPerPixel=1)),
 }
 name = sys.argv[1]
